@@ -1,0 +1,107 @@
+/*
+ * include/kws.h -- C ABI of the MI355X-native keyword-spotting hot path.
+ *
+ * The reference (david8862/tf-keras-speech-commands) has no FFI of its own: its
+ * hot path is Python calling sonopy and tf.keras.  This header is the boundary
+ * a maintainer would bind from that Python with ctypes;
+ * every entry point names the reference interface it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types; all array arguments are caller-owned
+ *     DEVICE pointers (row-major, float32 unless stated); `stream` is a
+ *     hipStream_t passed as void* (NULL = default stream);
+ *   - every int-returning function returns KWS_OK (0) or a negative kws_status;
+ *     kws_last_error() gives the message for the calling thread;
+ *   - work is only enqueued on `stream`; nothing synchronises the device;
+ *   - there is no CPU fallback: without a HIP device the create/launch calls
+ *     fail with KWS_ERR_HIP.
+ */
+#ifndef KWS_H
+#define KWS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum kws_status {
+    KWS_OK = 0,
+    KWS_ERR_INVALID = -1,     /* bad argument / inconsistent params              */
+    KWS_ERR_UNSUPPORTED = -2, /* valid in the reference, not built here yet      */
+    KWS_ERR_HIP = -3,         /* HIP runtime error (no device, launch failure)   */
+    KWS_ERR_NOMEM = -4,
+    KWS_ERR_WORKSPACE = -5    /* caller's workspace too small                    */
+} kws_status;
+
+const char *kws_version(void);
+const char *kws_last_error(void);
+/* number of visible HIP devices (0 when none / no driver); never fails */
+int kws_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Audio-pipeline parameters: the numeric fields of ListenerParams
+ * (classifier/params.py:49-59) as read from params.json (configs/params.json).
+ * ---------------------------------------------------------------------- */
+typedef struct kws_params {
+    double buffer_t, window_t, hop_t;
+    int32_t sample_rate, sample_depth, n_fft, n_filt, n_mfcc, use_delta;
+} kws_params;
+
+/* derived properties, classifier/params.py:59-91 */
+typedef struct kws_geometry {
+    int32_t window_samples, hop_samples, max_samples, buffer_samples, n_features, feature_size;
+} kws_geometry;
+
+/* defaults of classifier/params.py:99-103 */
+void kws_params_default(kws_params *p);
+/* host-only; KWS_ERR_INVALID if the parameters are unusable */
+int kws_params_derive(const kws_params *p, kws_geometry *g);
+
+/* ------------------------------------------------------------------------
+ * Featurizer: replaces common/data_utils.py:73-86 audio_to_feature (and with
+ * it vectorize_raw :61-70 = sonopy.mfcc_spec, and add_deltas :50-58), batched.
+ * KWS_BANK_BARK swaps in the filterbank of common/bark_feature.py:92-136
+ * (bfcc_spec :156-175).
+ * ---------------------------------------------------------------------- */
+typedef enum kws_bank_kind { KWS_BANK_MEL = 0, KWS_BANK_BARK = 1 } kws_bank_kind;
+typedef enum kws_wav_dtype {
+    KWS_WAV_F32 = 0, /* float32 in [-1,1), what librosa.load returns (data_utils.py:93) */
+    KWS_WAV_I16 = 1  /* raw little-endian PCM16, scaled by 1/32768 (data_utils.py:21)     */
+} kws_wav_dtype;
+
+typedef struct kws_featurizer kws_featurizer;
+
+int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **out);
+void kws_featurizer_destroy(kws_featurizer *f);
+/* geometry the featurizer was built for */
+int kws_featurizer_geometry(const kws_featurizer *f, kws_geometry *g);
+/* host copy of the dense (n_filt x (n_fft/2+1)) bank the sparse tables were built from */
+int kws_featurizer_bank(const kws_featurizer *f, float *host_bank, size_t count);
+
+/*
+ * wav      : (B, stride) samples of `wav_dtype`; row b holds clip b from its first sample
+ * valid_len: NULL (every clip has `stride` samples) or B DEVICE int32 clip lengths
+ *            (0 <= len <= stride).  Per clip the reference's contract applies: keep
+ *            the FIRST max_samples (data_utils.py:77), LEFT-pad with zeros when
+ *            shorter (:79-80).
+ * feat     : (B, n_features, feature_size) float32
+ */
+int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride,
+                  const int32_t *valid_len, float *feat, void *stream);
+
+/*
+ * vectorize_raw (common/data_utils.py:61-70): audio of exactly n_samples per clip, no length
+ * clipping, no padding, no deltas.  feat: (B, n_frames, n_mfcc) with
+ * n_frames = kws_featurize_raw_frames(f, n_samples) = (n_samples - window)/hop + 1 (0 if shorter).
+ */
+int kws_featurize_raw_frames(const kws_featurizer *f, int32_t n_samples);
+int kws_featurize_raw(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, int32_t n_samples,
+                      float *feat, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KWS_H */

@@ -1,0 +1,42 @@
+// csrc/kws_common.h -- shared host-side helpers for the C-ABI implementation (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "kws.h"
+
+namespace kws {
+
+std::string &last_error_slot();
+
+inline int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error_slot() = buf;
+    return code;
+}
+
+#define KWS_HIP_CHECK(expr)                                                                        \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return ::kws::fail(KWS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), \
+                               __FILE__, __LINE__);                                                \
+    } while (0)
+
+// kernel launches do not return a status; fetch the sticky launch error instead
+#define KWS_LAUNCH_CHECK(what)                                                                  \
+    do {                                                                                        \
+        hipError_t e__ = hipGetLastError();                                                     \
+        if (e__ != hipSuccess)                                                                  \
+            return ::kws::fail(KWS_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e__)); \
+    } while (0)
+
+}  // namespace kws

@@ -1,0 +1,569 @@
+// csrc/kws_featurize.hip -- fused waveform -> MFCC/BFCC featurizer for gfx950 (MI355X).
+//
+// Replaces common/data_utils.py:73-86 (audio_to_feature -> vectorize_raw -> sonopy.mfcc_spec,
+// optional add_deltas) of the reference for a whole batch in one launch.
+//
+// Mapping (n_fft = 1024 path):
+//   block  = one clip, kWaves wavefronts of 64 lanes;  wave w owns frames w, w+kWaves, ...
+//   frame  = 1024 real samples -> 512-point complex FFT done entirely inside ONE wave:
+//            each lane holds 8 complex points, three radix-8 passes (8x8x8) with two
+//            transposes through a per-wave 4.5 KB LDS tile (padded 72/9 so every half-wave
+//            ds_read/ds_write_b64 is bank-conflict free), then the real-FFT split,
+//            |X|^2/n_fft, a SPARSE band gather for the filterbank (per-lane chunks of one
+//            band's non-zero span; no dense GEMM), eps-clipped log, ortho DCT-II, c0 <- log energy.
+//   HBM    : every sample is requested once per frame it belongs to (2x with hop = window/2);
+//            the second touch is an L1/L2 hit issued by the same block, so DRAM traffic stays at
+//            the algorithmic 4 B/sample in + 4 B/feature out.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "kws_common.h"
+
+namespace kws {
+
+constexpr int kWaves = 5;                 // wavefronts per clip (30 default frames -> 6 frames each)
+constexpr int kThreads = kWaves * 64;
+constexpr int kFftTile = 8 * 72;          // float2 elements per wave (padded 8 x 64 tile)
+constexpr int kMaxChunks = 64;
+constexpr float kEps = 2.220446049250313e-16f;  // np.finfo(float).eps, common/bark_feature.py:77
+
+struct FeatDev {
+    int window_eff, hop, max_samples, n_frames, n_filt, n_out, feature_size, use_delta, nchunks, nnz;
+    float inv_nfft;
+    const float2 *tw1;   // [7][64]  W_512^(lane*k1), k1 = 1..7
+    const float2 *tw2;   // [7][8]   W_64^(l2*k2a),   k2a = 1..7
+    const float2 *tws;   // [257]    W_1024^k
+    const int4 *chunks;  // [nchunks] {band, first bin, count, offset into w}
+    const int *bcs;      // [n_filt+1] first chunk of each band
+    const float *w;      // [nnz] bank weights, chunk-major
+    const float *dct;    // [n_filt][n_out], ortho scaling folded in
+};
+
+}  // namespace kws
+
+struct kws_featurizer {
+    kws_params params;
+    kws_geometry geom;
+    int bank_kind;
+    std::vector<float> bank;  // dense host copy (n_filt x n_bins)
+    kws::FeatDev dev;
+    void *dmem;               // one device allocation holding every table
+    size_t smem_bytes;
+};
+
+namespace kws {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b)
+{
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // a * (-i)
+
+// forward 8-point DFT in registers, natural order in and out
+__device__ __forceinline__ void dft8(float2 (&v)[8])
+{
+    const float h = 0.70710678118654752440f;
+    float2 a0 = cadd(v[0], v[4]), a1 = csub(v[0], v[4]);
+    float2 a2 = cadd(v[2], v[6]), a3 = mul_mi(csub(v[2], v[6]));
+    float2 a4 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    float2 a6 = cadd(v[3], v[7]), a7 = mul_mi(csub(v[3], v[7]));
+    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = csub(a1, a3);
+    float2 b4 = cadd(a4, a6), b6 = csub(a4, a6), b5 = cadd(a5, a7), b7 = csub(a5, a7);
+    float2 t1 = make_float2(h * (b5.x + b5.y), h * (b5.y - b5.x));    // b5 * (1 - i)/sqrt2
+    float2 t2 = mul_mi(b6);                                           // b6 * (-i)
+    float2 t3 = make_float2(h * (b7.y - b7.x), -h * (b7.x + b7.y));   // b7 * (-1 - i)/sqrt2
+    v[0] = cadd(b0, b4); v[4] = csub(b0, b4);
+    v[1] = cadd(b1, t1); v[5] = csub(b1, t1);
+    v[2] = cadd(b2, t2); v[6] = csub(b2, t2);
+    v[3] = cadd(b3, t3); v[7] = csub(b3, t3);
+}
+
+// all 64 lanes of a wave run in lockstep and the LDS serves one wave's DS ops in order, so a
+// compiler-level fence is all an intra-wave LDS exchange needs
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(short v) { return (float)v * (1.0f / 32768.0f); }  // data_utils.py:21
+
+template <typename WavT> struct Vec2;
+template <> struct Vec2<float> { using type = float2; };
+template <> struct Vec2<short> { using type = short2; };
+
+__host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
+
+template <typename WavT>
+__global__ __launch_bounds__(kThreads) void featurize_fft1024_kernel(const WavT *__restrict__ wav, int64_t stride,
+                                                                      const int32_t *__restrict__ valid_len, int B,
+                                                                      FeatDev c, float *__restrict__ feat)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    if (b >= B) return;
+
+    float2 *s_fft = reinterpret_cast<float2 *>(smem) + wave * kFftTile;
+    float *s_pw = reinterpret_cast<float *>(s_fft);                       // power spectrum aliases the FFT tile
+    float *s_part = reinterpret_cast<float *>(smem + kWaves * kFftTile * 8) + wave * 128;
+    float *s_mel = s_part + 64;
+    unsigned char *blk = smem + kWaves * (kFftTile * 8 + 512);
+    int4 *s_chunks = reinterpret_cast<int4 *>(blk);                        // 64 x 16 B
+    int *s_bcs = reinterpret_cast<int *>(blk + 1024);                      // 68 ints
+    float *s_dct = reinterpret_cast<float *>(blk + 1024 + 272);
+    float *s_w = s_dct + round4(c.n_filt * c.n_out);
+    float *s_feat = s_w + round4(c.nnz);
+
+    for (int i = tid; i < c.nchunks; i += kThreads) s_chunks[i] = c.chunks[i];
+    for (int i = tid; i <= c.n_filt; i += kThreads) s_bcs[i] = c.bcs[i];
+    for (int i = tid; i < c.n_filt * c.n_out; i += kThreads) s_dct[i] = c.dct[i];
+    for (int i = tid; i < c.nnz; i += kThreads) s_w[i] = c.w[i];
+    __syncthreads();
+
+    // clip geometry: keep the head, left-pad zeros (data_utils.py:77-80)
+    int len = valid_len ? valid_len[b] : (stride > c.max_samples ? c.max_samples : (int)stride);
+    len = len < 0 ? 0 : len;
+    if ((int64_t)len > stride) len = (int)stride;
+    if (len > c.max_samples) len = c.max_samples;
+    const int pad = c.max_samples - len;
+    const WavT *src = wav + (int64_t)b * stride;
+    const bool vec_ok = (((pad | c.hop | c.window_eff) & 1) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(src) & (2 * sizeof(WavT) - 1)) == 0);
+
+    // per-lane twiddles, constant across frames
+    float2 tw1[7], tw2[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        tw1[k] = c.tw1[k * 64 + lane];
+        tw2[k] = c.tw2[k * 8 + (lane & 7)];
+    }
+    const int hi = lane >> 3, lo = lane & 7;
+
+    for (int f = wave; f < c.n_frames; f += kWaves) {
+        const int base = f * c.hop;
+        float2 v[8];
+        if (vec_ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int s0 = 2 * (lane + 64 * j), p0 = base + s0;
+                float2 val = make_float2(0.f, 0.f);
+                if (s0 < c.window_eff && p0 >= pad) {
+                    typename Vec2<WavT>::type t = *reinterpret_cast<const typename Vec2<WavT>::type *>(src + (p0 - pad));
+                    val = make_float2(to_f32(t.x), to_f32(t.y));
+                }
+                v[j] = val;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int s0 = 2 * (lane + 64 * j), p0 = base + s0;
+                float2 val = make_float2(0.f, 0.f);
+                if (s0 < c.window_eff && p0 >= pad) val.x = to_f32(src[p0 - pad]);
+                if (s0 + 1 < c.window_eff && p0 + 1 >= pad) val.y = to_f32(src[p0 + 1 - pad]);
+                v[j] = val;
+            }
+        }
+
+        // pass 1: DFT-8 over n1 (n = lane + 64 n1), twiddle W_512^(lane*k1)
+        dft8(v);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw1[k - 1]);
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_fft[72 * k + lane] = v[k];
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s_fft[72 * hi + lo + 8 * j];
+
+        // pass 2: lane = (k1, l2); DFT-8 over l1, twiddle W_64^(l2*k2a)
+        dft8(v);
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw2[k - 1]);
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_fft[72 * hi + 9 * k + lo] = v[k];
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = s_fft[72 * hi + 9 * lo + j];
+
+        // pass 3: lane = (k1, k2a); DFT-8 over l2 -> Z[k1 + 8 k2a + 64 k2b]
+        dft8(v);
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) s_fft[hi + 8 * lo + 64 * r] = v[r];
+        wave_sync();
+
+        // real-FFT split: X[k] = E[k] + W_1024^k O[k], X[512-k] = conj(E[k] - W_1024^k O[k])
+        float pk[4], pm[4], p256 = 0.f, energy = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
+            const float2 zk = s_fft[k], zm = s_fft[(512 - k) & 511];
+            const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            const float2 O = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+            const float2 T = cmul(c.tws[k], O);
+            const float2 xp = cadd(E, T), xm = csub(E, T);
+            pk[i] = (xp.x * xp.x + xp.y * xp.y) * c.inv_nfft;   // bark_feature.py:88-89
+            pm[i] = (xm.x * xm.x + xm.y * xm.y) * c.inv_nfft;
+            energy += pk[i] + pm[i];
+        }
+        if (lane == 0) {  // bin 256 is its own partner
+            const float2 z = s_fft[256];
+            p256 = (z.x * z.x + z.y * z.y) * c.inv_nfft;
+            energy += p256;
+        }
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = lane + 64 * i;
+            s_pw[k] = pk[i];
+            s_pw[512 - k] = pm[i];
+        }
+        if (lane == 0) s_pw[256] = p256;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) energy += __shfl_xor(energy, o, 64);
+        wave_sync();
+
+        // sparse band gather: lane = one chunk of one band's non-zero span
+        float part = 0.f;
+        if (lane < c.nchunks) {
+            const int4 ch = s_chunks[lane];
+            for (int t = 0; t < ch.z; ++t) part = fmaf(s_pw[ch.y + t], s_w[ch.w + t], part);
+        }
+        s_part[lane] = part;
+        wave_sync();
+        if (lane < c.n_filt) {
+            float s = 0.f;
+            for (int q = s_bcs[lane]; q < s_bcs[lane + 1]; ++q) s += s_part[q];
+            s_mel[lane] = logf(fmaxf(s, kEps));                 // safe_log, bark_feature.py:75-77
+        }
+        wave_sync();
+        if (lane < c.n_out) {
+            float s = 0.f;
+            for (int n = 0; n < c.n_filt; ++n) s = fmaf(s_mel[n], s_dct[n * c.n_out + lane], s);
+            if (lane == 0) s = logf(fmaxf(energy, kEps));       // c0 <- log energy, bark_feature.py:173
+            s_feat[f * c.n_out + lane] = s;
+        }
+        wave_sync();
+    }
+    __syncthreads();
+
+    // coalesced store of the clip's (n_features x feature_size) block; add_deltas fused (data_utils.py:50-58)
+    float *dst = feat + (int64_t)b * c.n_frames * c.feature_size;
+    const int total = c.n_frames * c.feature_size;
+    for (int i = tid; i < total; i += kThreads) {
+        const int fr = i / c.feature_size, col = i - fr * c.feature_size;
+        float val;
+        if (col < c.n_out) val = s_feat[fr * c.n_out + col];
+        else val = fr == 0 ? 0.f : s_feat[fr * c.n_out + col - c.n_out] - s_feat[(fr - 1) * c.n_out + col - c.n_out];
+        dst[i] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: parameter geometry and table construction (double precision, then rounded once)
+// ---------------------------------------------------------------------------------------------
+static int derive(const kws_params *p, kws_geometry *g)
+{
+    if (!p || !g) return fail(KWS_ERR_INVALID, "null params");
+    if (p->sample_rate <= 0 || p->window_t <= 0 || p->hop_t <= 0 || p->buffer_t <= 0)
+        return fail(KWS_ERR_INVALID, "sample_rate/window_t/hop_t/buffer_t must be positive");
+    // classifier/params.py:59-91
+    g->window_samples = (int)(p->sample_rate * p->window_t + 0.5);
+    g->hop_samples = (int)(p->sample_rate * p->hop_t + 0.5);
+    g->max_samples = (int)(p->buffer_t * p->sample_rate);
+    if (g->hop_samples <= 0 || g->window_samples <= 0) return fail(KWS_ERR_INVALID, "window/hop round to zero samples");
+    int samples = (int)(p->sample_rate * p->buffer_t + 0.5);
+    g->buffer_samples = g->hop_samples * (samples / g->hop_samples);
+    g->n_features = 1 + (int)std::floor((double)(g->buffer_samples - g->window_samples) / (double)g->hop_samples);
+    g->feature_size = p->use_delta ? 2 * p->n_mfcc : p->n_mfcc;
+    return KWS_OK;
+}
+
+static int build_mel_bank(int sample_rate, int n_fft, int n_filt, std::vector<double> &bank)
+{
+    // sonopy.filterbanks as restated by inference/tflite/mfcc.h:230-264; span 0..sample_rate
+    // (inference/tflite/speech_commands.h:304-307)
+    const int n_bins = n_fft / 2 + 1, n = n_filt + 2;
+    std::vector<int> pts(n);
+    const double lo = 1127.0 * std::log(1.0 + 0.0 / 700.0), hi = 1127.0 * std::log(1.0 + sample_rate / 700.0);
+    const double step = (hi - lo) / (double)(n - 1);
+    for (int i = 0; i < n; ++i) {
+        const double m = (i == n - 1) ? hi : lo + i * step;
+        pts[i] = (int)(700.0 * (std::exp(m / 1127.0) - 1.0) * n_bins / sample_rate);
+    }
+    for (int i = 1; i < n; ++i)
+        if (pts[i] <= pts[i - 1])
+            return fail(KWS_ERR_UNSUPPORTED, "mel grid has repeated FFT bins for n_fft=%d n_filt=%d (sonopy's "
+                                             "duplicate-point correction is not implemented)", n_fft, n_filt);
+    if (pts[n - 1] > n_bins) return fail(KWS_ERR_INVALID, "mel grid exceeds the spectrum");
+    bank.assign((size_t)n_filt * n_bins, 0.0);
+    for (int i = 0; i < n_filt; ++i) {
+        const int l = pts[i], m = pts[i + 1], r = pts[i + 2];
+        for (int j = l; j < m; ++j) bank[(size_t)i * n_bins + j] = (double)(j - l) / (double)(m - l);
+        for (int j = m; j < r; ++j) bank[(size_t)i * n_bins + j] = (double)(r - j) / (double)(r - m);
+    }
+    return KWS_OK;
+}
+
+static int build_bark_bank(int sample_rate, int n_fft, int n_filt, std::vector<double> &bank)
+{
+    // common/bark_feature.py:92-136 with scale="constant".  The bin<->Hz maps at :112/:134 are
+    // called with their DEFAULT nfft=512 and sample_rate=16000 whatever the caller passes; kept.
+    const int n_bins = n_fft / 2 + 1, n = n_filt + 4;
+    auto hz2bark = [](double f) { return 6.0 * std::asinh(f / 600.0); };
+    auto bark2hz = [](double v) { return 600.0 * std::sinh(v / 6.0); };
+    auto Fm = [](double fb, double fc) {
+        if (fc - 2.5 <= fb && fb <= fc - 0.5) return std::pow(10.0, 2.5 * (fb - fc + 0.5));
+        if (fc - 0.5 < fb && fb < fc + 0.5) return 1.0;
+        if (fc + 0.5 <= fb && fb <= fc + 1.3) return std::pow(10.0, -2.5 * (fb - fc - 0.5));
+        return 0.0;
+    };
+    const double lo = hz2bark(0.0), hi = hz2bark(sample_rate / 2.0), step = (hi - lo) / (double)(n - 1);
+    std::vector<double> pt(n);
+    std::vector<int> bins(n);
+    for (int i = 0; i < n; ++i) {
+        pt[i] = (i == n - 1) ? hi : lo + i * step;
+        bins[i] = (int)std::floor(513.0 * bark2hz(pt[i]) / 16000.0);
+    }
+    bank.assign((size_t)n_filt * n_bins, 0.0);
+    for (int i = 0; i < n_filt; ++i)
+        for (int j = bins[i]; j < bins[i + 4]; ++j) {
+            if (j < 0 || j >= n_bins) return fail(KWS_ERR_INVALID, "bark bank needs bin %d but n_fft=%d has %d", j, n_fft, n_bins);
+            bank[(size_t)i * n_bins + j] = std::fabs(Fm(hz2bark(j * 16000.0 / 513.0), pt[i + 2]));
+        }
+    return KWS_OK;
+}
+
+}  // namespace kws
+
+using namespace kws;
+
+extern "C" {
+
+void kws_params_default(kws_params *p)
+{
+    if (!p) return;
+    // classifier/params.py:99-103
+    p->buffer_t = 1.0; p->window_t = 0.064; p->hop_t = 0.032;
+    p->sample_rate = 16000; p->sample_depth = 2; p->n_fft = 1024; p->n_filt = 20; p->n_mfcc = 20; p->use_delta = 0;
+}
+
+int kws_params_derive(const kws_params *p, kws_geometry *g) { return derive(p, g); }
+
+int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **out)
+{
+    if (!p || !out) return fail(KWS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    kws_geometry g;
+    int rc = derive(p, &g);
+    if (rc) return rc;
+    if (bank_kind != KWS_BANK_MEL && bank_kind != KWS_BANK_BARK) return fail(KWS_ERR_INVALID, "unknown bank kind %d", bank_kind);
+    if (p->n_filt < 1 || p->n_filt > 64) return fail(KWS_ERR_UNSUPPORTED, "n_filt must be in 1..64, got %d", p->n_filt);
+    if (p->n_mfcc < 1 || p->n_mfcc > p->n_filt)
+        return fail(KWS_ERR_INVALID, "n_mfcc=%d must be in 1..n_filt=%d (the reference's feature_size would not match)", p->n_mfcc, p->n_filt);
+    if (p->n_fft != 1024) return fail(KWS_ERR_UNSUPPORTED, "only n_fft=1024 has a HIP kernel so far (got %d)", p->n_fft);
+    if (g.max_samples < g.window_samples) return fail(KWS_ERR_INVALID, "buffer shorter than one window");
+    const int n_frames = (g.max_samples - g.window_samples) / g.hop_samples + 1;
+    if (n_frames != g.n_features)
+        return fail(KWS_ERR_INVALID, "params give %d frames but n_features=%d; the reference's model input would not match", n_frames, g.n_features);
+
+    std::vector<double> bank;
+    rc = bank_kind == KWS_BANK_MEL ? build_mel_bank(p->sample_rate, p->n_fft, p->n_filt, bank)
+                                   : build_bark_bank(p->sample_rate, p->n_fft, p->n_filt, bank);
+    if (rc) return rc;
+    const int n_bins = p->n_fft / 2 + 1, n_filt = p->n_filt, n_out = p->n_mfcc;
+
+    // sparse tables: per band the span [first non-zero, last non-zero], cut into <= 64 lane chunks
+    std::vector<int> first(n_filt, 0), width(n_filt, 0);
+    for (int i = 0; i < n_filt; ++i) {
+        int a = -1, z = -1;
+        for (int j = 0; j < n_bins; ++j)
+            if (bank[(size_t)i * n_bins + j] != 0.0) { if (a < 0) a = j; z = j; }
+        if (a >= 0) { first[i] = a; width[i] = z - a + 1; }
+    }
+    int ch = 1;
+    for (;; ++ch) {
+        int cnt = 0;
+        for (int i = 0; i < n_filt; ++i) cnt += (width[i] + ch - 1) / ch;
+        if (cnt <= kMaxChunks) break;
+    }
+    std::vector<int4> chunks;
+    std::vector<int> bcs(n_filt + 1, 0);
+    std::vector<float> w;
+    for (int i = 0; i < n_filt; ++i) {
+        bcs[i] = (int)chunks.size();
+        for (int off = 0; off < width[i]; off += ch) {
+            const int cnt = std::min(ch, width[i] - off);
+            chunks.push_back(make_int4(i, first[i] + off, cnt, (int)w.size()));
+            for (int t = 0; t < cnt; ++t) w.push_back((float)bank[(size_t)i * n_bins + first[i] + off + t]);
+        }
+    }
+    bcs[n_filt] = (int)chunks.size();
+
+    std::vector<float2> tw1(7 * 64), tw2(7 * 8), tws(257);
+    for (int k = 1; k < 8; ++k)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * M_PI * (double)(l * k) / 512.0;
+            tw1[(k - 1) * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k = 1; k < 8; ++k)
+        for (int l = 0; l < 8; ++l) {
+            const double a = -2.0 * M_PI * (double)(l * k) / 64.0;
+            tw2[(k - 1) * 8 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k = 0; k <= 256; ++k) {
+        const double a = -2.0 * M_PI * (double)k / 1024.0;
+        tws[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    std::vector<float> dct((size_t)n_filt * n_out);
+    for (int n = 0; n < n_filt; ++n)
+        for (int k = 0; k < n_out; ++k)  // scipy dct type II norm='ortho' (bark_feature.py:172, mfcc.h:55-67)
+            dct[(size_t)n * n_out + k] = (float)(std::cos(M_PI * (n + 0.5) * k / n_filt) * (k == 0 ? std::sqrt(1.0 / n_filt) : std::sqrt(2.0 / n_filt)));
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return fail(KWS_ERR_HIP, "no HIP device: the featurizer has no CPU fallback");
+    }
+
+    auto *f = new kws_featurizer();
+    f->params = *p; f->geom = g; f->bank_kind = bank_kind;
+    f->bank.resize(bank.size());
+    for (size_t i = 0; i < bank.size(); ++i) f->bank[i] = (float)bank[i];
+
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_tw1 = 0, o_tw2 = al(o_tw1 + tw1.size() * 8), o_tws = al(o_tw2 + tw2.size() * 8),
+                 o_ch = al(o_tws + tws.size() * 8), o_bcs = al(o_ch + std::max<size_t>(1, chunks.size()) * 16),
+                 o_w = al(o_bcs + bcs.size() * 4), o_dct = al(o_w + std::max<size_t>(1, w.size()) * 4),
+                 total = al(o_dct + dct.size() * 4);
+    std::vector<unsigned char> host(total, 0);
+    std::memcpy(host.data() + o_tw1, tw1.data(), tw1.size() * 8);
+    std::memcpy(host.data() + o_tw2, tw2.data(), tw2.size() * 8);
+    std::memcpy(host.data() + o_tws, tws.data(), tws.size() * 8);
+    if (!chunks.empty()) std::memcpy(host.data() + o_ch, chunks.data(), chunks.size() * 16);
+    std::memcpy(host.data() + o_bcs, bcs.data(), bcs.size() * 4);
+    if (!w.empty()) std::memcpy(host.data() + o_w, w.data(), w.size() * 4);
+    std::memcpy(host.data() + o_dct, dct.data(), dct.size() * 4);
+    hipError_t e = hipMalloc(&f->dmem, total);
+    if (e == hipSuccess) e = hipMemcpy(f->dmem, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (f->dmem) (void)hipFree(f->dmem);
+        delete f;
+        return fail(KWS_ERR_HIP, "featurizer table upload failed: %s", hipGetErrorString(e));
+    }
+    auto *base = static_cast<unsigned char *>(f->dmem);
+    FeatDev &d = f->dev;
+    d.window_eff = std::min(g.window_samples, (int)p->n_fft);  // np.fft.rfft(frames, n): crop or zero-pad (bark_feature.py:87)
+    d.hop = g.hop_samples; d.max_samples = g.max_samples; d.n_frames = n_frames;
+    d.n_filt = n_filt; d.n_out = n_out; d.feature_size = g.feature_size; d.use_delta = p->use_delta ? 1 : 0;
+    d.nchunks = (int)chunks.size(); d.nnz = (int)w.size(); d.inv_nfft = 1.0f / (float)p->n_fft;
+    d.tw1 = reinterpret_cast<const float2 *>(base + o_tw1);
+    d.tw2 = reinterpret_cast<const float2 *>(base + o_tw2);
+    d.tws = reinterpret_cast<const float2 *>(base + o_tws);
+    d.chunks = reinterpret_cast<const int4 *>(base + o_ch);
+    d.bcs = reinterpret_cast<const int *>(base + o_bcs);
+    d.w = reinterpret_cast<const float *>(base + o_w);
+    d.dct = reinterpret_cast<const float *>(base + o_dct);
+    f->smem_bytes = (size_t)kWaves * (kFftTile * 8 + 512) + 1024 + 272 +
+                    4 * (size_t)(round4(n_filt * n_out) + round4(d.nnz) + round4(n_frames * n_out));
+    if (f->smem_bytes > 64 * 1024) {
+        (void)hipFree(f->dmem);
+        delete f;
+        return fail(KWS_ERR_UNSUPPORTED, "featurizer needs %zu B of LDS (> 160 KiB)", f->smem_bytes);
+    }
+    *out = f;
+    return KWS_OK;
+}
+
+void kws_featurizer_destroy(kws_featurizer *f)
+{
+    if (!f) return;
+    if (f->dmem) (void)hipFree(f->dmem);
+    delete f;
+}
+
+int kws_featurizer_geometry(const kws_featurizer *f, kws_geometry *g)
+{
+    if (!f || !g) return fail(KWS_ERR_INVALID, "null argument");
+    *g = f->geom;
+    return KWS_OK;
+}
+
+int kws_featurizer_bank(const kws_featurizer *f, float *host_bank, size_t count)
+{
+    if (!f || !host_bank) return fail(KWS_ERR_INVALID, "null argument");
+    if (count != f->bank.size()) return fail(KWS_ERR_INVALID, "bank has %zu floats, caller asked for %zu", f->bank.size(), count);
+    std::memcpy(host_bank, f->bank.data(), count * sizeof(float));
+    return KWS_OK;
+}
+
+static size_t feat_smem_bytes(const FeatDev &d)
+{
+    return (size_t)kWaves * (kFftTile * 8 + 512) + 1024 + 272 +
+           4 * (size_t)(round4(d.n_filt * d.n_out) + round4(d.nnz) + round4(d.n_frames * d.n_out));
+}
+
+static int launch_featurize(const FeatDev &d, const void *wav, int wav_dtype, int B, int64_t stride,
+                            const int32_t *valid_len, float *feat, void *stream)
+{
+    const size_t smem = feat_smem_bytes(d);
+    if (smem > 160 * 1024) return fail(KWS_ERR_UNSUPPORTED, "%d frames need %zu B of LDS (> 160 KiB)", d.n_frames, smem);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)B), block(kThreads);
+    if (wav_dtype == KWS_WAV_F32) {
+        if (smem > 64 * 1024)
+            KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_fft1024_kernel<float>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(featurize_fft1024_kernel<float>, grid, block, smem, s, static_cast<const float *>(wav), stride,
+                           valid_len, B, d, feat);
+    } else if (wav_dtype == KWS_WAV_I16) {
+        if (smem > 64 * 1024)
+            KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_fft1024_kernel<short>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(featurize_fft1024_kernel<short>, grid, block, smem, s, static_cast<const short *>(wav), stride,
+                           valid_len, B, d, feat);
+    } else {
+        return fail(KWS_ERR_INVALID, "unknown wav dtype %d", wav_dtype);
+    }
+    KWS_LAUNCH_CHECK("featurize_fft1024_kernel");
+    return KWS_OK;
+}
+
+int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, const int32_t *valid_len,
+                  float *feat, void *stream)
+{
+    if (!f || !feat || (!wav && B > 0)) return fail(KWS_ERR_INVALID, "null argument");
+    if (B < 0 || stride < 0) return fail(KWS_ERR_INVALID, "negative batch or stride");
+    if (B == 0) return KWS_OK;
+    if (!valid_len && stride < 1) return fail(KWS_ERR_INVALID, "stride must be >= 1 when valid_len is NULL");
+    return launch_featurize(f->dev, wav, wav_dtype, B, stride, valid_len, feat, stream);
+}
+
+int kws_featurize_raw_frames(const kws_featurizer *f, int32_t n_samples)
+{
+    if (!f || n_samples < f->geom.window_samples) return 0;  // chop_array, bark_feature.py:80-82
+    return (n_samples - f->geom.window_samples) / f->geom.hop_samples + 1;
+}
+
+int kws_featurize_raw(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, int32_t n_samples,
+                      float *feat, void *stream)
+{
+    if (!f || !feat || (!wav && B > 0)) return fail(KWS_ERR_INVALID, "null argument");
+    if (B < 0 || n_samples < 0 || stride < n_samples) return fail(KWS_ERR_INVALID, "bad batch / n_samples / stride");
+    FeatDev d = f->dev;
+    d.n_frames = kws_featurize_raw_frames(f, n_samples);
+    if (B == 0 || d.n_frames == 0) return KWS_OK;  // sonopy returns an empty matrix
+    d.max_samples = n_samples;
+    d.use_delta = 0;
+    d.feature_size = d.n_out;
+    return launch_featurize(d, wav, wav_dtype, B, stride, nullptr, feat, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""ctypes bindings of include/kws.h."""
+import ctypes
+import os
+
+from .build import LIB_PATH
+
+
+class KwsError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("kws error %d: %s" % (code, message))
+        self.code = code
+
+
+class KwsParams(ctypes.Structure):
+    _fields_ = [("buffer_t", ctypes.c_double), ("window_t", ctypes.c_double), ("hop_t", ctypes.c_double),
+                ("sample_rate", ctypes.c_int32), ("sample_depth", ctypes.c_int32), ("n_fft", ctypes.c_int32),
+                ("n_filt", ctypes.c_int32), ("n_mfcc", ctypes.c_int32), ("use_delta", ctypes.c_int32)]
+
+
+class KwsGeometry(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("window_samples", "hop_samples", "max_samples", "buffer_samples", "n_features", "feature_size")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+BANK_MEL, BANK_BARK = 0, 1
+WAV_F32, WAV_I16 = 0, 1
+
+_lib = None
+
+
+def get_lib():
+    """Load libkws_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libkws_hip.so is missing at %s: build it with `python -m kws_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+    L.kws_version.restype = ctypes.c_char_p
+    L.kws_last_error.restype = ctypes.c_char_p
+    L.kws_device_count.restype = i32
+    L.kws_params_default.argtypes = [ctypes.POINTER(KwsParams)]
+    L.kws_params_default.restype = None
+    L.kws_params_derive.argtypes = [ctypes.POINTER(KwsParams), ctypes.POINTER(KwsGeometry)]
+    L.kws_featurizer_create.argtypes = [ctypes.POINTER(KwsParams), i32, ctypes.POINTER(vp)]
+    L.kws_featurizer_destroy.argtypes = [vp]
+    L.kws_featurizer_destroy.restype = None
+    L.kws_featurizer_geometry.argtypes = [vp, ctypes.POINTER(KwsGeometry)]
+    L.kws_featurizer_bank.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t]
+    L.kws_featurize.argtypes = [vp, vp, i32, i32, i64, vp, fp, vp]
+    L.kws_featurize_raw.argtypes = [vp, vp, i32, i32, i64, i32, fp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise KwsError(rc, get_lib().kws_last_error().decode("utf-8", "replace"))
+
+
+def version():
+    return get_lib().kws_version().decode()
+
+
+def device_count():
+    return get_lib().kws_device_count()

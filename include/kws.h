@@ -101,6 +101,69 @@ int kws_featurize_raw_frames(const kws_featurizer *f, int32_t n_samples);
 int kws_featurize_raw(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, int32_t n_samples,
                       float *feat, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Model: replaces the tf.keras objects built by classifier/model.py:14-46
+ * get_model() (backbones classifier/models/cnn.py, rnn.py) and the work
+ * Keras does inside model.fit / model.predict (train.py:75-92).
+ *
+ * Weights live in two caller-owned flat float32 device buffers:
+ *   params : the trainable tensors           (kws_model_param_count floats)
+ *   state  : BatchNormalization moving stats (kws_model_state_count floats)
+ * kws_model_tensor_info() enumerates the tensors in Keras get_weights() order
+ * with their offset into params (trainable) or state (not trainable); offsets
+ * are multiples of 4 floats, gaps are zero.  grads / Adam moments mirror params.
+ * ---------------------------------------------------------------------- */
+typedef enum kws_model_kind {
+    KWS_SIMPLE_CNN = 0,      /* classifier/models/cnn.py:11-74  */
+    KWS_SIMPLE_CNN_LITE = 1, /* classifier/models/cnn.py:77-141 */
+    KWS_SIMPLE_GRU = 2,      /* classifier/models/rnn.py:10-43  */
+    KWS_SIMPLE_LSTM = 3      /* classifier/models/rnn.py:46-79  */
+} kws_model_kind;
+
+typedef struct kws_model kws_model;
+
+typedef struct kws_tensor_info {
+    char name[64];      /* e.g. "conv2d/kernel", "batch_normalization/gamma", "score_predict/bias" */
+    int32_t ndim;
+    int32_t shape[4];   /* Keras shapes: conv HWIO, dense (in, out) */
+    int32_t trainable;  /* 1: offset is into params, 0: into state */
+    int64_t offset;     /* in floats */
+    int64_t size;       /* in floats */
+} kws_tensor_info;
+
+/* host only (no GPU needed).  kind outside the enum -> KWS_ERR_INVALID "Unsupported model type"
+ * (classifier/model.py:32). n_features / feature_size: classifier/params.py:66-68,86-91. */
+int kws_model_create(int kind, int num_classes, int n_features, int feature_size, kws_model **out);
+void kws_model_destroy(kws_model *m);
+int64_t kws_model_param_count(const kws_model *m);
+int64_t kws_model_state_count(const kws_model *m);
+int kws_model_num_tensors(const kws_model *m);
+int kws_model_tensor_info(const kws_model *m, int index, kws_tensor_info *out);
+/* bytes of 256-byte aligned device scratch the calls below need for batch B */
+int64_t kws_model_workspace_bytes(const kws_model *m, int B, int training);
+
+/* model.predict (inference mode: BN moving statistics, no dropout).
+ * feat (B, n_features, feature_size) -> probs (B, C) and/or argmax (B) (either may be NULL). */
+int kws_model_forward(kws_model *m, const float *feat, int B, const float *params, const float *state, void *ws,
+                      size_t ws_bytes, float *probs, int32_t *argmax, void *stream);
+
+/* One training forward + backward (what Keras does per batch inside model.fit, train.py:81):
+ * batch-statistics BN (moving stats in `state` are updated), dropout from `dropout_seed` (0 = off),
+ * loss = classifier/loss.py SparseCategoricalCrossEntropy (class_weights NULL) or
+ * WeightedSparseCategoricalCrossEntropy (class_weights: C device floats), reduced by the batch mean.
+ * grads <- grad_scale * d(mean loss)/d(params)  (data parallel: grad_scale = 1/world, then sum-all-reduce).
+ * stats (2 device floats, may be NULL) <- {sum of per-sample losses, number of top-1 hits};
+ * probs (B, C) may be NULL. */
+int kws_model_train_fwd_bwd(kws_model *m, const float *feat, const int32_t *labels, const float *class_weights, int B,
+                            const float *params, float *state, float *grads, void *ws, size_t ws_bytes,
+                            uint64_t dropout_seed, float grad_scale, float *probs, float *stats, void *stream);
+
+/* keras.optimizers.Adam update (common/model_utils.py:47) on flat buffers of n floats, step count t >= 1:
+ *   lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m/(sqrt(v)+eps)
+ * with g = grad_scale * grads. */
+int kws_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int64_t t, float grad_scale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,151 @@
+"""GPU parity tests of the HIP model path (through the C ABI) against the numpy oracle (oracle/model_oracle.py).
+Tolerances follow north_star: class-index argmax bit-exact, probabilities / loss within 1e-3 (fp32 vs float64 oracle);
+gradients are compared relative to each tensor's largest entry."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def build(model_type, C, seed=0, perturb=True):
+    from kws_amd.model import DeviceModel, ModelSpec
+    from oracle import model_oracle as mo
+    om = mo.Model(model_type, C).init_weights(seed)
+    if perturb:
+        rng = np.random.default_rng(seed + 1)
+        ws = om.get_weights()
+        for i, (li, n, t) in enumerate(om.weight_list()):
+            if n in ("gamma", "moving_variance"):
+                ws[i] = ws[i] * rng.uniform(0.5, 1.5, ws[i].shape)
+            elif n in ("beta", "bias", "moving_mean"):
+                ws[i] = ws[i] + 0.1 * rng.standard_normal(ws[i].shape)
+        om.set_weights(ws)
+    spec = ModelSpec(model_type, C, 30, 20)
+    dm = DeviceModel(spec)
+    dm.set_weights(om.get_weights())
+    return om, dm
+
+
+def rel_err(got, want):
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+
+
+def features(B, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, 30, 20)) * 3.0
+    x[..., 0] -= 10.0   # MFCC-like: a large negative c0 column
+    return x.astype(np.float32)
+
+
+def test_tensor_table_is_keras_order(torch):
+    from kws_amd.model import ModelSpec
+    from oracle import model_oracle as mo
+    spec = ModelSpec("simple_cnn", 36, 30, 20)
+    om = mo.Model("simple_cnn", 36)
+    assert spec.trainable_count() == om.trainable_count() == 134932
+    assert spec.non_trainable_count() == 480
+    assert [t["shape"] for t in spec.tensors] == [w.shape for w in om.get_weights()]
+    assert spec.tensors[0]["name"] == "conv2d/kernel" and spec.tensors[-1]["name"] == "score_predict/bias"
+    assert [t["trainable"] for t in spec.tensors[:5]] == [True, True, True, False, False]
+
+
+@pytest.mark.parametrize("B", [1, 5, 64, 100])
+def test_cnn_inference_forward(torch, B):
+    om, dm = build("simple_cnn", 36)
+    x = features(B, 3)
+    probs, am = dm.forward(torch.from_numpy(x).cuda())
+    want = om.predict(x.astype(np.float64))
+    np.testing.assert_allclose(probs.cpu().numpy(), want, atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
+
+
+@pytest.mark.parametrize("weighted,seed", [(False, 0), (True, 0), (False, 0x1234ABCD5678)])
+def test_cnn_train_forward_backward(torch, weighted, seed):
+    from oracle import model_oracle as mo
+    C, B = 36, 48
+    om, dm = build("simple_cnn", C)
+    x = features(B, 5)
+    y = np.random.default_rng(6).integers(0, C, B)
+    cw = np.array([0.3] + [0.7 / (C - 1)] * (C - 1)) if weighted else None
+    state0 = [w.copy() for w in om.get_weights()]
+    loss, acc, p = mo.train_forward_backward(om, x.astype(np.float64), y, cw, dropout_seed=seed or None)
+    probs = dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(),
+                             torch.from_numpy(cw.astype(np.float32)).cuda() if weighted else None, dropout_seed=seed,
+                             want_probs=True)
+    stats = dm.stats.cpu().numpy()
+    np.testing.assert_allclose(probs.cpu().numpy(), p, atol=1e-4, rtol=0)
+    assert abs(stats[0] / B - loss) < 1e-4
+    assert stats[1] == round(acc * B)
+    worst = 0.0
+    for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
+        e = rel_err(g, want)
+        worst = max(worst, e)
+        assert e < 2e-4, "gradient of layer %d %s: rel err %g" % (li, n, e)
+    # BatchNormalization moving statistics were updated like Keras does (momentum 0.99, unbiased variance)
+    got_w = dm.get_weights()
+    for i, (li, n, t) in enumerate(om.weight_list()):
+        if not t:
+            np.testing.assert_allclose(got_w[i], om.get_weights()[i], rtol=2e-5, atol=1e-6, err_msg=n)
+            assert not np.allclose(got_w[i], state0[i])
+
+
+def test_cnn_multi_step_training_tracks_oracle(torch):
+    """10 Adam steps with dropout: loss trajectory within 1e-3 of the float64 oracle, weights stay close."""
+    from oracle import model_oracle as mo
+    C, B = 5, 64
+    om, dm = build("simple_cnn", C, seed=2, perturb=False)
+    rng = np.random.default_rng(11)
+    protos = rng.standard_normal((C, 30, 20)) * 2
+    opt = mo.Adam(1e-3)
+    for it in range(10):
+        y = rng.integers(0, C, B)
+        x = (protos[y] + 0.5 * rng.standard_normal((B, 30, 20))).astype(np.float32)
+        seed = 1000 + it
+        lo, _ = mo.train_step(om, opt, x.astype(np.float64), y, dropout_seed=seed)
+        dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(), dropout_seed=seed)
+        dm.adam_step(1e-3)
+        lg = float(dm.stats[0].item()) / B
+        assert abs(lg - lo) < 1e-3, (it, lg, lo)
+    for got, want, (li, n, t) in zip(dm.get_weights(), om.get_weights(), om.weight_list()):
+        assert rel_err(got, want) < 2e-3, (li, n)
+
+
+def test_adam_step_matches_keras_form(torch):
+    from kws_amd.model import DeviceModel, ModelSpec
+    from oracle import model_oracle as mo
+    dm = DeviceModel(ModelSpec("simple_cnn", 5, 30, 20))
+    n = dm.params.numel()
+    rng = np.random.default_rng(0)
+    p = rng.standard_normal(n).astype(np.float32)
+    dm.params.copy_(torch.from_numpy(p))
+    opt, ref = mo.Adam(1e-3), [p.astype(np.float64)]
+    for t in range(3):
+        g = (rng.standard_normal(n) * 10.0 ** rng.integers(-9, 1, n)).astype(np.float32)
+        dm.grads.copy_(torch.from_numpy(g))
+        dm.adam_step(1e-3)
+        ref = opt.step(ref, [g.astype(np.float64)])
+    np.testing.assert_allclose(dm.params.cpu().numpy(), ref[0], atol=2e-6, rtol=1e-5)
+
+
+def test_workspace_and_argument_errors(torch):
+    from kws_amd import KwsError
+    from kws_amd import lib as l
+    from kws_amd.model import DeviceModel, ModelSpec
+    spec = ModelSpec("simple_cnn", 5, 30, 20)
+    dm = DeviceModel(spec)
+    x = torch.zeros((4, 30, 20), device="cuda")
+    small = torch.empty((1024,), dtype=torch.uint8, device="cuda")
+    base = (small.data_ptr() + 255) & ~255
+    rc = l.get_lib().kws_model_forward(spec.handle, x.data_ptr(), 4, dm.params.data_ptr(), dm.state.data_ptr(), base, 512, 0, 0, 0)
+    assert rc == -5 and b"workspace too small" in l.get_lib().kws_last_error()
+    with pytest.raises(ValueError, match="Unsupported model type"):
+        ModelSpec("resnet50", 5, 30, 20)
+    with pytest.raises(KwsError):
+        ModelSpec("simple_cnn", 5, 3, 3)   # too small for four conv/pool stages

@@ -1,0 +1,283 @@
+// csrc/kws_conv.h -- implicit-GEMM convolution / dense kernels on the fp32 MFMA (v_mfma_f32_16x16x4_f32).
+//
+// Everything GEMM-shaped in simple_cnn (Conv2D 3x3 'same', classifier/models/cnn.py:27-58; Dense 256->128, :64) is
+// one of three products over NHWC activations and HWIO (Keras-order) weights:
+//   FWD    z[m][n]   = sum_{tap,c} x[pix(m)+tap][c]      * W[tap][c][n]        m = output pixel, n = out channel
+//   DGRAD  dx[m][n]  = sum_{tap,c} dz[pixT(m,tap)][c]    * W[tap][n][c]        m = input pixel,  n = in channel
+//   WGRAD  dW[tap][c][n] = sum_m   x[pix(m)+tap][c]      * dz[m][n]
+// fp32 MFMA is bit-exact fp32 (a k-ordered fmaf chain), so parity with the fp32/fp64 oracle needs no extra slack.
+//
+// Tiling (one 256-thread block = 4 waves):
+//   FWD/DGRAD: 64 rows x all CO columns per block; wave w owns rows 16w..16w+15 and CO/16 accumulator tiles.  The K
+//              loop walks (tap, KC-channel chunk); the A tile (64 x KC, gathered rows, zero for padding) and the
+//              B tile (KC x CO) are staged through LDS with the next chunk's global loads in flight during the MFMAs.
+//   WGRAD:     the block owns a pixel range and a group of taps; per 64-pixel step it stages dz (64 x COUT) and the
+//              tap-shifted x tiles, the 16x16 output tiles are dealt round-robin to the 4 waves, and the partial dW
+//              is added to global memory with float atomics (the pixel range is split over many blocks).
+// LDS strides are chosen so that every half-wave ds_read_b32 of a fragment is bank-conflict free
+// (row stride == 2 mod 32 words for A[row][k], == 16 mod 32 for [k][col] tiles).
+#pragma once
+#include "kws_device.h"
+
+namespace kws {
+
+struct ConvGeom {
+    int B, H, W, Ho, Wo;   // input and output spatial sizes (NHWC)
+    int stride, pt, pl;    // TF 'SAME': pad_top / pad_left (the extra pad, if any, is bottom/right)
+    int KH, KW;
+};
+
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_BIAS_RELU6 = 2 };
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+__host__ __device__ constexpr int stride16(int c) { return (c % 32 == 16) ? c : c + 16; }   // == 16 (mod 32)
+
+// ---------------------------------------------------------------------------------------------------------------
+// FWD / DGRAD.  CR = channels reduced per tap, CO = channels produced.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CR, int CO, int MODE, int EPI>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict__ src, const float *__restrict__ wgt,
+                                                         const float *__restrict__ bias, float *__restrict__ dst,
+                                                         ConvGeom g)
+{
+    constexpr int KC = CR >= 32 ? 32 : CR;
+    constexpr int SA = KC + 2;                 // A tile row stride (words): 2*row + q -> 32 distinct banks
+    constexpr int SB = stride16(CO);
+    constexpr int NT = CO / 16;
+    constexpr int A4 = KC / 4;                 // float4 units per A row
+    constexpr int NA = (64 * A4 + 255) / 256;
+    constexpr int BUNITS = KC * CO / 4;
+    constexpr int NB = (BUNITS + 255) / 256;
+    constexpr int CPT = CR / KC;               // chunks per tap
+    static_assert(CR % KC == 0 && CO % 16 == 0 && KC % 4 == 0, "channel counts must be multiples of 16");
+
+    __shared__ __attribute__((aligned(16))) float As[64 * SA];
+    __shared__ __attribute__((aligned(16))) float Bs[KC * SB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+    // rows of this GEMM: output pixels (FWD) or input pixels (DGRAD)
+    const int RH = MODE == MODE_FWD ? g.Ho : g.H, RW = MODE == MODE_FWD ? g.Wo : g.W;
+    const int SH = MODE == MODE_FWD ? g.H : g.Ho, SW = MODE == MODE_FWD ? g.W : g.Wo;   // source spatial size
+    const long M = (long)g.B * RH * RW;
+    const long m0 = (long)blockIdx.x * 64;
+    const int ntaps = g.KH * g.KW, nchunks = ntaps * CPT;
+
+    // per-thread A-staging coordinates (fixed over the K loop)
+    int a_row[NA], a_c4[NA], a_b[NA], a_y[NA], a_x[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int u = tid + 256 * j;
+        a_row[j] = u / A4;
+        a_c4[j] = u % A4;
+        const long m = m0 + a_row[j];
+        if (u < 64 * A4 && m < M) {
+            const int pix = (int)(m % ((long)RH * RW));
+            a_b[j] = (int)(m / ((long)RH * RW));
+            a_y[j] = pix / RW;
+            a_x[j] = pix % RW;
+        } else {
+            a_b[j] = -1; a_y[j] = 0; a_x[j] = 0;
+        }
+    }
+
+    float4 ra[NA], rb[NB];
+    auto load_chunk = [&](int chunk) {
+        const int tap = chunk / CPT, c0 = (chunk % CPT) * KC;
+        const int kh = tap / g.KW, kw = tap % g.KW;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a_b[j] >= 0) {
+                int sy, sx;
+                bool ok;
+                if (MODE == MODE_FWD) {
+                    sy = a_y[j] * g.stride + kh - g.pt;
+                    sx = a_x[j] * g.stride + kw - g.pl;
+                    ok = sy >= 0 && sy < SH && sx >= 0 && sx < SW;
+                } else {
+                    const int ty = a_y[j] + g.pt - kh, tx = a_x[j] + g.pl - kw;
+                    sy = ty / g.stride; sx = tx / g.stride;
+                    ok = ty >= 0 && tx >= 0 && ty % g.stride == 0 && tx % g.stride == 0 && sy < SH && sx < SW;
+                }
+                if (ok) v = *reinterpret_cast<const float4 *>(src + (((long)a_b[j] * SH + sy) * SW + sx) * CR + c0 + a_c4[j] * 4);
+            }
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int u = tid + 256 * j;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < BUNITS) {
+                if (MODE == MODE_FWD) {
+                    const int kk = u / (CO / 4), n4 = u % (CO / 4);
+                    v = *reinterpret_cast<const float4 *>(wgt + ((long)(tap * CR + c0 + kk)) * CO + n4 * 4);
+                } else {
+                    const int n = u / A4, k4 = u % A4;    // W[tap][n][c0 + 4*k4 ..]: HWIO with I = CO, O = CR
+                    v = *reinterpret_cast<const float4 *>(wgt + ((long)(tap * CO + n)) * CR + c0 + k4 * 4);
+                }
+            }
+            rb[j] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int u = tid + 256 * j;
+            if (u < 64 * A4) {
+                float *p = &As[a_row[j] * SA + a_c4[j] * 4];      // 8-byte aligned: SA even
+                *reinterpret_cast<float2 *>(p) = make_float2(ra[j].x, ra[j].y);
+                *reinterpret_cast<float2 *>(p + 2) = make_float2(ra[j].z, ra[j].w);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int u = tid + 256 * j;
+            if (u < BUNITS) {
+                if (MODE == MODE_FWD) {
+                    const int kk = u / (CO / 4), n4 = u % (CO / 4);
+                    *reinterpret_cast<float4 *>(&Bs[kk * SB + n4 * 4]) = rb[j];
+                } else {
+                    const int n = u / A4, k4 = u % A4;
+                    Bs[(k4 * 4 + 0) * SB + n] = rb[j].x;
+                    Bs[(k4 * 4 + 1) * SB + n] = rb[j].y;
+                    Bs[(k4 * 4 + 2) * SB + n] = rb[j].z;
+                    Bs[(k4 * 4 + 3) * SB + n] = rb[j].w;
+                }
+            }
+        }
+    };
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const float a = As[(16 * wave + li) * SA + kk + lq];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = mfma16(a, Bs[(kk + lq) * SB + 16 * t + li], acc[t]);
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = 16 * t + li;
+        float bv = 0.f;
+        if (EPI == EPI_BIAS_RELU6) bv = bias[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = m0 + 16 * wave + 4 * lq + r;
+            if (m < M) {
+                float v = acc[t][r];
+                if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                if (EPI == EPI_BIAS_RELU6) v = relu6f(v + bv);
+                dst[m * CO + n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// WGRAD.  CB = min(CIN, 64) input channels per k-group; a block owns GPB consecutive (tap, channel-block) groups.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int GPB>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
+                                                          float *__restrict__ dw, ConvGeom g, int steps_per_block)
+{
+    constexpr int CB = CIN >= 64 ? 64 : CIN;
+    constexpr int CBLK = CIN / CB;             // channel blocks per tap
+    constexpr int SX = stride16(CB), SD = stride16(COUT);
+    constexpr int MT = CB / 16, NT = COUT / 16;
+    constexpr int T = GPB * MT * NT;           // 16x16 output tiles owned by the block
+    constexpr int TPW = (T + 3) / 4;           // tiles per wave
+    constexpr int X4 = CB / 4, D4 = COUT / 4;
+    static_assert(CIN % CB == 0 && CB % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ds = smem;                          // [64][SD]
+    float *Xs = smem + 64 * SD;                // [GPB][64][SX]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    const int ngroups = g.KH * g.KW * CBLK;
+    const int grp0 = blockIdx.y * GPB;
+    const long mbeg = (long)blockIdx.x * steps_per_block * 64;
+
+    f32x4 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int step = 0; step < steps_per_block; ++step) {
+        const long ms = mbeg + (long)step * 64;
+        if (ms >= M) break;
+        __syncthreads();                       // previous step's MFMAs are done with the tiles
+        for (int u = tid; u < 64 * D4; u += 256) {
+            const int row = u / D4, c4 = u % D4;
+            const long m = ms + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M) v = *reinterpret_cast<const float4 *>(dz + m * COUT + c4 * 4);
+            *reinterpret_cast<float4 *>(&Ds[row * SD + c4 * 4]) = v;
+        }
+        for (int u = tid; u < GPB * 64 * X4; u += 256) {
+            const int gi = u / (64 * X4), rem = u % (64 * X4), row = rem / X4, c4 = rem % X4;
+            const int grp = grp0 + gi;
+            const long m = ms + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grp < ngroups && m < M) {
+                const int tap = grp / CBLK, cb = (grp % CBLK) * CB;
+                const int kh = tap / g.KW, kw = tap % g.KW;
+                const int pix = (int)(m % ((long)g.Ho * g.Wo)), b = (int)(m / ((long)g.Ho * g.Wo));
+                const int sy = (pix / g.Wo) * g.stride + kh - g.pt, sx = (pix % g.Wo) * g.stride + kw - g.pl;
+                if (sy >= 0 && sy < g.H && sx >= 0 && sx < g.W)
+                    v = *reinterpret_cast<const float4 *>(x + (((long)b * g.H + sy) * g.W + sx) * CIN + cb + c4 * 4);
+            }
+            *reinterpret_cast<float4 *>(&Xs[(gi * 64 + row) * SX + c4 * 4]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mm = 0; mm < 64; mm += 4) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tile = wave + 4 * t;
+                if (tile < T) {
+                    const int gi = tile / (MT * NT), mt = (tile / NT) % MT, nt = tile % NT;
+                    const float a = Xs[(gi * 64 + mm + lq) * SX + 16 * mt + li];   // A^T: row = channel, k = pixel
+                    const float bv = Ds[(mm + lq) * SD + 16 * nt + li];
+                    acc[t] = mfma16(a, bv, acc[t]);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tile = wave + 4 * t;
+        if (tile < T) {
+            const int gi = tile / (MT * NT), mt = (tile / NT) % MT, nt = tile % NT;
+            const int grp = grp0 + gi;
+            if (grp < ngroups) {
+                const int tap = grp / CBLK, cb = (grp % CBLK) * CB;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = cb + 16 * mt + 4 * lq + r, co = 16 * nt + li;
+                    atomicAdd(dw + ((long)(tap * CIN + ci)) * COUT + co, acc[t][r]);
+                }
+            }
+        }
+    }
+}
+
+template <int CIN, int COUT, int GPB>
+constexpr size_t conv_wgrad_smem()
+{
+    constexpr int CB = CIN >= 64 ? 64 : CIN;
+    return sizeof(float) * (size_t)(64 * stride16(COUT) + GPB * 64 * stride16(CB));
+}
+
+}  // namespace kws

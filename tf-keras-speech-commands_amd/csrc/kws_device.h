@@ -1,0 +1,47 @@
+// csrc/kws_device.h -- device-side helpers shared by the model kernels (gfx950 / wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kws {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fmaf chain), 64 lanes compute a 16x16 tile, K = 4.
+//   A operand: lane l holds A[row = l & 15][k = l >> 4]
+//   B operand: lane l holds B[k = l >> 4][col = l & 15]
+//   C/D      : lane l holds D[row = 4*(l >> 4) + r][col = l & 15] in register r
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Counter-based dropout keep decision, bit-identical to oracle/model_oracle.py:dropout_keep
+__device__ __forceinline__ bool dropout_keep(uint32_t seed_lo, uint32_t seed_hi, uint32_t index, float rate)
+{
+    uint32_t h = index ^ seed_lo;
+    h += seed_hi * 0x9E3779B9u;
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return (float)(h >> 8) * (1.0f / 16777216.0f) >= rate;
+}
+
+__device__ __forceinline__ float relu6f(float x) { return fminf(fmaxf(x, 0.f), 6.f); }
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace kws

@@ -1,0 +1,405 @@
+// csrc/kws_layers.h -- the non-GEMM kernels of the train / inference step (gfx950).
+//   conv1 (Cin = 1) direct kernels, BatchNormalization statistics / apply / backward, ReLU6 + 2x2 max-pool,
+//   inverted dropout, the softmax head with the reference's two losses, and the Keras-form Adam update.
+// Reference semantics: classifier/models/cnn.py:27-66, classifier/loss.py:21-77, common/model_utils.py:47 and the
+// Keras layer defaults listed in SURVEY.md section 7.
+#pragma once
+#include "kws_device.h"
+
+namespace kws {
+
+constexpr float kBnEps = 1e-3f;        // BatchNormalization(epsilon=1e-3)
+constexpr double kBnMomentum = 0.99;   // BatchNormalization(momentum=0.99)
+constexpr float kCeEps = 1e-7f;        // keras.backend.epsilon()
+
+// ---- conv1: 3x3 'same', Cin = 1 -> COUT (cnn.py:27-31) --------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         float *__restrict__ z, int B, int H, int W)
+{
+    __shared__ float ws[9 * COUT];
+    for (int i = threadIdx.x; i < 9 * COUT; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long M = (long)B * H * W, m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const int pix = (int)(m % (H * W)), b = (int)(m / (H * W)), oh = pix / W, ow = pix % W;
+    float v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+        v[t] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? x[((long)b * H + ih) * W + iw] : 0.f;
+    }
+    float4 *dst = reinterpret_cast<float4 *>(z + m * COUT);
+#pragma unroll
+    for (int c4 = 0; c4 < COUT / 4; ++c4) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(v[t], ws[t * COUT + c4 * 4 + e], o[e]);
+        dst[c4] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dW[tap][co] += sum_m x[pix(m)+tap] * dz[m][co]; thread = (pixel lane, co), block partials -> atomics
+template <int COUT>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
+                                                           float *__restrict__ dw, int B, int H, int W, int rows_per_block)
+{
+    constexpr int R = 256 / COUT;
+    const int co = threadIdx.x % COUT, r = threadIdx.x / COUT;
+    const long M = (long)B * H * W, beg = (long)blockIdx.x * rows_per_block;
+    const long end = beg + rows_per_block < M ? beg + rows_per_block : M;
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long m = beg + r; m < end; m += R) {
+        const float d = dz[m * COUT + co];
+        const int pix = (int)(m % (H * W)), b = (int)(m / (H * W)), oh = pix / W, ow = pix % W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
+            if (ih >= 0 && ih < H && iw >= 0 && iw < W) acc[t] = fmaf(x[((long)b * H + ih) * W + iw], d, acc[t]);
+        }
+    }
+    __shared__ float sh[9][256];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) sh[t][threadIdx.x] = acc[t];
+    __syncthreads();
+    if (threadIdx.x < 9 * COUT) {
+        const int t = threadIdx.x / COUT, c = threadIdx.x % COUT;
+        float s = 0.f;
+        for (int j = 0; j < R; ++j) s += sh[t][j * COUT + c];
+        atomicAdd(dw + t * COUT + c, s);
+    }
+}
+
+// ---- per-channel sums over the rows of an (M x C) matrix, in double -------------------------------------------
+// partial[(blk*2 + 0)*C + c] = sum, [(blk*2 + 1)*C + c] = sum of squares.  C divides 256.
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float *__restrict__ z, long M, int C, int rows_per_block,
+                                                             double *__restrict__ partial)
+{
+    const int c = threadIdx.x % C, r = threadIdx.x / C, R = 256 / C;
+    const long beg = (long)blockIdx.x * rows_per_block;
+    const long end = beg + rows_per_block < M ? beg + rows_per_block : M;
+    double s = 0.0, ss = 0.0;
+    for (long m = beg + r; m < end; m += R) {
+        const double v = (double)z[m * C + c];
+        s += v;
+        ss += v * v;
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    if (r == 0) {
+        for (int j = 1; j < R; ++j) { s += sh[0][j * C + c]; ss += sh[1][j * C + c]; }
+        partial[((long)blockIdx.x * 2 + 0) * C + c] = s;
+        partial[((long)blockIdx.x * 2 + 1) * C + c] = ss;
+    }
+}
+
+struct BnCoef {      // per-layer float arrays of C entries each, contiguous: scale, shift, mean, inv, k2, k3
+    float *scale, *shift, *mean, *inv, *k2, *k3;
+};
+
+// training: batch statistics (biased variance normalises; the moving variance takes the unbiased estimate)
+__global__ void bn_finalize_train_kernel(const double *__restrict__ partial, int nblk, long M, int C,
+                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                         float *__restrict__ moving_mean, float *__restrict__ moving_var, BnCoef k)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[((long)b * 2 + 0) * C + c]; ss += partial[((long)b * 2 + 1) * C + c]; }
+    const double mean = s / (double)M;
+    double var = ss / (double)M - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const double inv = 1.0 / sqrt(var + (double)kBnEps);
+    const double sc = (double)gamma[c] * inv;
+    k.scale[c] = (float)sc;
+    k.shift[c] = (float)((double)beta[c] - mean * sc);
+    k.mean[c] = (float)mean;
+    k.inv[c] = (float)inv;
+    const double unbiased = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+    moving_mean[c] = (float)((double)moving_mean[c] * kBnMomentum + mean * (1.0 - kBnMomentum));
+    moving_var[c] = (float)((double)moving_var[c] * kBnMomentum + unbiased * (1.0 - kBnMomentum));
+}
+
+// inference: moving statistics
+__global__ void bn_infer_coef_kernel(int C, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                     const float *__restrict__ moving_mean, const float *__restrict__ moving_var, BnCoef k)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double inv = 1.0 / sqrt((double)moving_var[c] + (double)kBnEps);
+    const double sc = (double)gamma[c] * inv;
+    k.scale[c] = (float)sc;
+    k.shift[c] = (float)((double)beta[c] - (double)moving_mean[c] * sc);
+    k.mean[c] = moving_mean[c];
+    k.inv[c] = (float)inv;
+}
+
+// y = relu6(z*scale + shift), optional 2x2/2 'valid' max-pool, optional inverted dropout on the result
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const float *__restrict__ z, const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, float *__restrict__ a, int B,
+                                                           int H, int W, int C, float drop_rate, uint32_t seed_lo,
+                                                           uint32_t seed_hi)
+{
+    const int Hp = POOL ? H / 2 : H, Wp = POOL ? W / 2 : W;
+    const long total = (long)B * Hp * Wp * C, idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    long t = idx / C;
+    const int pw = (int)(t % Wp);
+    t /= Wp;
+    const int ph = (int)(t % Hp), b = (int)(t / Hp);
+    const float sc = scale[c], sh = shift[c];
+    float v;
+    if (POOL) {
+        const float *p = z + (((long)b * H + 2 * ph) * W + 2 * pw) * C + c;
+        v = fmaxf(fmaxf(fmaf(p[0], sc, sh), fmaf(p[C], sc, sh)),
+                  fmaxf(fmaf(p[(long)W * C], sc, sh), fmaf(p[(long)W * C + C], sc, sh)));
+    } else {
+        v = fmaf(z[idx], sc, sh);
+    }
+    v = relu6f(v);
+    if (drop_rate > 0.f) v = dropout_keep(seed_lo, seed_hi, (uint32_t)idx, drop_rate) ? v / (1.f - drop_rate) : 0.f;
+    a[idx] = v;
+}
+
+// backward through dropout / max-pool / ReLU6 to the BN output: writes g = dL/dy per z element and the per-channel
+// partial sums of g and g*xhat (double).  The pool routes the gradient to the FIRST maximum of its window.
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restrict__ z, const float *__restrict__ da,
+                                                             BnCoef k, float *__restrict__ gz, int B, int H, int W, int C,
+                                                             int rows_per_block, double *__restrict__ partial,
+                                                             float drop_rate, uint32_t seed_lo, uint32_t seed_hi)
+{
+    const int c = threadIdx.x % C, r = threadIdx.x / C, R = 256 / C;
+    const int Hp = POOL ? H / 2 : H, Wp = POOL ? W / 2 : W;
+    const long M = (long)B * H * W, beg = (long)blockIdx.x * rows_per_block;
+    const long end = beg + rows_per_block < M ? beg + rows_per_block : M;
+    const float sc = k.scale[c], sh = k.shift[c], mean = k.mean[c], inv = k.inv[c];
+    double s = 0.0, sx = 0.0;
+    for (long m = beg + r; m < end; m += R) {
+        const int pix = (int)(m % ((long)H * W)), b = (int)(m / ((long)H * W)), ih = pix / W, iw = pix % W;
+        const float zv = z[m * C + c];
+        const float y = fmaf(zv, sc, sh);
+        float g = 0.f;
+        if (POOL) {
+            const int ph = ih >> 1, pw = iw >> 1;
+            if (ph < Hp && pw < Wp) {
+                const float *p = z + (((long)b * H + 2 * ph) * W + 2 * pw) * C + c;
+                const float v0 = relu6f(fmaf(p[0], sc, sh)), v1 = relu6f(fmaf(p[C], sc, sh));
+                const float v2 = relu6f(fmaf(p[(long)W * C], sc, sh)), v3 = relu6f(fmaf(p[(long)W * C + C], sc, sh));
+                int arg = 0;
+                float best = v0;
+                if (v1 > best) { best = v1; arg = 1; }
+                if (v2 > best) { best = v2; arg = 2; }
+                if (v3 > best) { best = v3; arg = 3; }
+                if (arg == (ih & 1) * 2 + (iw & 1)) {
+                    const long oidx = (((long)b * Hp + ph) * Wp + pw) * C + c;
+                    g = da[oidx];
+                    if (drop_rate > 0.f) g = dropout_keep(seed_lo, seed_hi, (uint32_t)oidx, drop_rate) ? g / (1.f - drop_rate) : 0.f;
+                }
+            }
+        } else {
+            g = da[m * C + c];
+            if (drop_rate > 0.f) g = dropout_keep(seed_lo, seed_hi, (uint32_t)(m * C + c), drop_rate) ? g / (1.f - drop_rate) : 0.f;
+        }
+        g = (y > 0.f && y < 6.f) ? g : 0.f;
+        gz[m * C + c] = g;
+        s += (double)g;
+        sx += (double)g * (double)((zv - mean) * inv);
+    }
+    __shared__ double shm[2][256];
+    shm[0][threadIdx.x] = s;
+    shm[1][threadIdx.x] = sx;
+    __syncthreads();
+    if (r == 0) {
+        for (int j = 1; j < R; ++j) { s += shm[0][j * C + c]; sx += shm[1][j * C + c]; }
+        partial[((long)blockIdx.x * 2 + 0) * C + c] = s;
+        partial[((long)blockIdx.x * 2 + 1) * C + c] = sx;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblk, long M, int C,
+                                       const float *__restrict__ gamma, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta, BnCoef k)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += partial[((long)b * 2 + 0) * C + c]; sx += partial[((long)b * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)sx;
+    k.k2[c] = (float)(s / (double)M);
+    k.k3[c] = (float)(sx / (double)M);
+}
+
+// dz = gamma*inv * (g - mean(g) - xhat * mean(g*xhat)); RELU_IN additionally gates by the conv's own relu (cnn.py:55)
+template <bool RELU_IN>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restrict__ z, float *__restrict__ gz, BnCoef k,
+                                                            const float *__restrict__ gamma, long total, int C)
+{
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const float zv = z[idx];
+    const float xhat = (zv - k.mean[c]) * k.inv[c];
+    float d = gamma[c] * k.inv[c] * (gz[idx] - k.k2[c] - xhat * k.k3[c]);
+    if (RELU_IN) d = zv > 0.f ? d : 0.f;
+    gz[idx] = d;
+}
+
+// ---- head: Dense(C, softmax) 'score_predict' (classifier/model.py:37) + loss (classifier/loss.py) --------------
+// block = 16 samples.  logits -> probs, per-sample loss / correct flag, dlogits = d(mean loss)/d(logits) * grad_scale
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ d1, const float *__restrict__ w2,
+                                                        const float *__restrict__ b2, const int32_t *__restrict__ labels,
+                                                        const float *__restrict__ class_w, float *__restrict__ probs,
+                                                        int32_t *__restrict__ argmax_out, float *__restrict__ loss_i,
+                                                        float *__restrict__ correct_i, float *__restrict__ dlogits, int B,
+                                                        int K, int C, float grad_scale)
+{
+    extern __shared__ float hs[];
+    float *xs = hs;              // [16][K]
+    float *lg = hs + 16 * K;     // [16][C]
+    const int b0 = blockIdx.x * 16;
+    for (int i = threadIdx.x; i < 16 * K; i += 256) {
+        const int s = i / K;
+        xs[i] = (b0 + s < B) ? d1[(long)(b0 + s) * K + (i % K)] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * C; i += 256) {
+        const int s = i / C, c = i % C;
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(xs[s * K + k], w2[(long)k * C + c], acc);
+        lg[i] = acc + b2[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && b0 + threadIdx.x < B) {
+        const int s = threadIdx.x, b = b0 + s;
+        float mx = lg[s * C];
+        int am = 0;
+        for (int c = 1; c < C; ++c)
+            if (lg[s * C + c] > mx) { mx = lg[s * C + c]; am = c; }
+        float sum = 0.f;
+        for (int c = 0; c < C; ++c) { const float e = expf(lg[s * C + c] - mx); lg[s * C + c] = e; sum += e; }
+        const float rs = 1.f / sum;
+        if (argmax_out) argmax_out[b] = am;
+        if (probs)
+            for (int c = 0; c < C; ++c) probs[(long)b * C + c] = lg[s * C + c] * rs;
+        if (labels) {
+            const int y = labels[b];
+            const float py = lg[s * C + y] * rs;
+            float loss, coef;
+            if (class_w) {                       // loss.py:67-71: -log(p_y) * w_y, no clipping
+                loss = -logf(py) * class_w[y];
+                coef = class_w[y];
+            } else {                             // loss.py:36: K.categorical_crossentropy on probabilities (clipped)
+                const float lo = kCeEps, hi = 1.f - kCeEps;
+                loss = -logf(fminf(fmaxf(py, lo), hi));
+                coef = (py >= lo && py <= hi) ? 1.f : 0.f;
+            }
+            loss_i[b] = loss;
+            correct_i[b] = am == y ? 1.f : 0.f;
+            if (dlogits)
+                for (int c = 0; c < C; ++c)
+                    dlogits[(long)b * C + c] = (lg[s * C + c] * rs - (c == y ? 1.f : 0.f)) * coef * grad_scale;
+        }
+    }
+}
+
+// deterministic sum of per-sample losses / correct flags: out[0] = sum(loss), out[1] = sum(correct)
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restrict__ loss_i, const float *__restrict__ correct_i,
+                                                           int B, float *__restrict__ out)
+{
+    double s = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) { s += (double)loss_i[i]; c += (double)correct_i[i]; }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s;
+    sh[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = (float)sh[0][0]; out[1] = (float)sh[1][0]; }
+}
+
+// head backward: dx[b][k] = sum_c dlogits[b][c] W2[k][c], gated by the ReLU6 of x (x = relu6 output: 0 < x < 6);
+// dW2[k][c] += sum_b x[b][k] dlogits[b][c]; db2[c] += sum_b dlogits[b][c].  block = 64 samples.
+template <bool RELU6_GATE>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w2,
+                                                        const float *__restrict__ dlogits, float *__restrict__ dx,
+                                                        float *__restrict__ dw2, float *__restrict__ db2, int B, int K, int C)
+{
+    extern __shared__ float hs[];
+    float *xs = hs;              // [64][K]
+    float *ds = hs + 64 * K;     // [64][C]
+    const int b0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * K; i += 256) xs[i] = (b0 + i / K < B) ? x[(long)(b0 + i / K) * K + (i % K)] : 0.f;
+    for (int i = threadIdx.x; i < 64 * C; i += 256) ds[i] = (b0 + i / C < B) ? dlogits[(long)(b0 + i / C) * C + (i % C)] : 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * K; i += 256) {
+        const int s = i / K, k = i % K;
+        if (b0 + s >= B) continue;
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(ds[s * C + c], w2[(long)k * C + c], acc);
+        if (RELU6_GATE) { const float xv = xs[i]; acc = (xv > 0.f && xv < 6.f) ? acc : 0.f; }
+        dx[(long)(b0 + s) * K + k] = acc;
+    }
+    for (int i = threadIdx.x; i < K * C; i += 256) {
+        const int k = i / C, c = i % C;
+        float acc = 0.f;
+        for (int s = 0; s < 64; ++s) acc = fmaf(xs[s * K + k], ds[s * C + c], acc);
+        atomicAdd(dw2 + i, acc);
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int s = 0; s < 64; ++s) acc += ds[s * C + c];
+        atomicAdd(db2 + c, acc);
+    }
+}
+
+// per-column sums of an (M x C) matrix into out[C] (bias gradients); reuses the double partial slab
+__global__ void colsum_finalize_kernel(const double *__restrict__ partial, int nblk, int C, float *__restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[((long)b * 2 + 0) * C + c];
+    out[c] = (float)s;
+}
+
+// ---- keras.optimizers.Adam (common/model_utils.py:47): eps OUTSIDE the bias correction -----------------------
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                    float *__restrict__ v, long n, float lr_t, float b1, float b2, float eps,
+                                                    float grad_scale)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        float4 pv = *reinterpret_cast<float4 *>(p + i), gv = *reinterpret_cast<const float4 *>(g + i);
+        float4 mv = *reinterpret_cast<float4 *>(m + i), vv = *reinterpret_cast<float4 *>(v + i);
+        float *pp = &pv.x, *gp = &gv.x, *mp = &mv.x, *vp = &vv.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ge = gp[e] * grad_scale;
+            mp[e] = b1 * mp[e] + (1.f - b1) * ge;
+            vp[e] = b2 * vp[e] + (1.f - b2) * ge * ge;
+            pp[e] -= lr_t * mp[e] / (sqrtf(vp[e]) + eps);
+        }
+        *reinterpret_cast<float4 *>(p + i) = pv;
+        *reinterpret_cast<float4 *>(m + i) = mv;
+        *reinterpret_cast<float4 *>(v + i) = vv;
+    } else {
+        for (long j = i; j < n; ++j) {
+            const float ge = g[j] * grad_scale;
+            m[j] = b1 * m[j] + (1.f - b1) * ge;
+            v[j] = b2 * v[j] + (1.f - b2) * ge * ge;
+            p[j] -= lr_t * m[j] / (sqrtf(v[j]) + eps);
+        }
+    }
+}
+
+}  // namespace kws

@@ -1,0 +1,410 @@
+// csrc/kws_model.hip -- model descriptors and the simple_cnn forward / backward behind the C ABI.
+//
+// Topology follows classifier/models/cnn.py:27-66 (SimpleCNN) and the softmax head of classifier/model.py:37.
+// Flat buffers: `params` holds the trainable tensors and `state` the BatchNormalization moving statistics, both
+// in Keras get_weights() order (kws_model_tensor_info lists name / shape / offset); `grads` mirrors `params`.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kws_common.h"
+#include "kws_conv.h"
+#include "kws_layers.h"
+
+using namespace kws;
+
+namespace {
+
+struct Tensor {
+    std::string name;
+    std::vector<int> shape;
+    bool trainable;
+    int64_t offset, size;
+};
+
+struct CnnDims { int H0, W0, H1, W1, H2, W2, H3, W3, H4, W4, flat; };
+
+inline int64_t al4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int same_out(int n, int s) { return (n + s - 1) / s; }
+inline int same_pad_before(int n, int k, int s)
+{
+    const int out = same_out(n, s), total = std::max((out - 1) * s + k - n, 0);
+    return total / 2;   // TF 'SAME': the extra element goes to the end
+}
+
+}  // namespace
+
+struct kws_model {
+    int kind, C, n_features, feature_size;
+    std::vector<Tensor> tensors;
+    int64_t P = 0, S = 0;
+    CnnDims d{};
+    // offsets into params / state for simple_cnn
+    int64_t o_k[4], o_g[4], o_b[4], o_dk, o_db, o_hk, o_hb, o_mm[4], o_mv[4];
+
+    int64_t add(const std::string &name, std::vector<int> shape, bool trainable)
+    {
+        int64_t n = 1;
+        for (int s : shape) n *= s;
+        int64_t &cur = trainable ? P : S;
+        const int64_t off = cur;
+        tensors.push_back({name, shape, trainable, off, n});
+        cur = al4(cur + n);
+        return off;
+    }
+};
+
+namespace {
+
+constexpr int kCh[5] = {1, 16, 32, 64, 128};
+constexpr int kMaxStatBlocks = 1024;
+
+// ---- workspace layout (simple_cnn) ---------------------------------------------------------------------------
+struct CnnWs {
+    float *z[4], *a[4], *d1, *logits_unused, *loss_i, *correct_i, *dlogits, *dd1, *da4, *gz[4], *da[3];
+    float *coef[4];     // 6*C floats per BN layer
+    double *partial;    // [kMaxStatBlocks][2][256]
+    size_t bytes;
+};
+
+CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
+{
+    CnnWs w{};
+    size_t off = 0;
+    auto take = [&](size_t nfloats) {
+        float *p = reinterpret_cast<float *>(base + off);
+        off = al256(off + nfloats * sizeof(float));
+        return p;
+    };
+    const CnnDims &d = m->d;
+    const size_t zs[4] = {(size_t)d.H0 * d.W0 * 16, (size_t)d.H1 * d.W1 * 32, (size_t)d.H3 * d.W3 * 64, (size_t)d.H3 * d.W3 * 128};
+    const size_t as[4] = {(size_t)d.H1 * d.W1 * 16, (size_t)d.H2 * d.W2 * 32, (size_t)d.H3 * d.W3 * 64, (size_t)d.flat};
+    for (int i = 0; i < 4; ++i) { w.z[i] = take(zs[i] * B); w.a[i] = take(as[i] * B); }
+    w.d1 = take((size_t)B * 128);
+    w.loss_i = take(B);
+    w.correct_i = take(B);
+    for (int i = 0; i < 4; ++i) w.coef[i] = take(6 * 128);
+    w.partial = reinterpret_cast<double *>(take((size_t)kMaxStatBlocks * 2 * 256 * 2));
+    if (training) {
+        w.dlogits = take((size_t)B * m->C);
+        w.dd1 = take((size_t)B * 128);
+        w.da4 = take((size_t)B * d.flat);
+        for (int i = 0; i < 4; ++i) w.gz[i] = take(zs[i] * B);
+        for (int i = 0; i < 3; ++i) w.da[i] = take(as[i] * B);
+    }
+    w.bytes = off;
+    return w;
+}
+
+BnCoef coef_of(float *base, int C) { return BnCoef{base, base + C, base + 2 * C, base + 3 * C, base + 4 * C, base + 5 * C}; }
+
+inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// rows-per-block and grid for the (M x C) channel reductions
+inline void stat_grid(long M, int C, int &nblk, int &rows)
+{
+    const int R = 256 / C;
+    long want = (M + (long)R * 8 - 1) / ((long)R * 8);
+    nblk = (int)std::min<long>(kMaxStatBlocks, std::max<long>(1, want));
+    rows = (int)((M + nblk - 1) / nblk);
+    nblk = (int)((M + rows - 1) / rows);
+}
+
+template <int CR, int CO, int MODE, int EPI>
+void launch_gemm(const float *src, const float *w, const float *bias, float *dst, const ConvGeom &g, hipStream_t s)
+{
+    const long M = (long)g.B * (MODE == MODE_FWD ? g.Ho * g.Wo : g.H * g.W);
+    hipLaunchKernelGGL((conv_gemm_kernel<CR, CO, MODE, EPI>), dim3(blocks_for(M, 64)), dim3(256), 0, s, src, w, bias, dst, g);
+}
+
+template <int CIN, int COUT, int GPB>
+void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s)
+{
+    constexpr int CB = CIN >= 64 ? 64 : CIN;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    const int ngroups = g.KH * g.KW * (CIN / CB), gy = (ngroups + GPB - 1) / GPB;
+    const long steps = (M + 63) / 64;
+    long gx = std::max<long>(1, std::min<long>(steps, 1024 / gy));
+    const int spb = (int)((steps + gx - 1) / gx);
+    gx = (steps + spb - 1) / spb;
+    const size_t smem = conv_wgrad_smem<CIN, COUT, GPB>();
+    hipLaunchKernelGGL((conv_wgrad_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), smem, s, x, dz, dw, g, spb);
+}
+
+ConvGeom geom3x3(int B, int H, int W, int stride)
+{
+    ConvGeom g;
+    g.B = B; g.H = H; g.W = W; g.stride = stride; g.KH = 3; g.KW = 3;
+    g.Ho = same_out(H, stride); g.Wo = same_out(W, stride);
+    g.pt = same_pad_before(H, 3, stride); g.pl = same_pad_before(W, 3, stride);
+    return g;
+}
+
+// ---- forward ------------------------------------------------------------------------------------------------
+int cnn_forward(const kws_model *m, const float *feat, int B, const float *params, float *state, CnnWs &w, bool training,
+                uint64_t seed, hipStream_t s)
+{
+    const CnnDims &d = m->d;
+    const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};   // conv input sizes
+    const int Hz[4] = {d.H0, d.H1, d.H3, d.H3}, Wz[4] = {d.W0, d.W1, d.W3, d.W3};   // conv output sizes
+    const bool pool[4] = {true, true, false, true};
+    const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
+
+    for (int l = 0; l < 4; ++l) {
+        const float *in = l == 0 ? feat : w.a[l - 1];
+        const float *kern = params + m->o_k[l];
+        const long M = (long)B * Hz[l] * Wz[l];
+        const int C = kCh[l + 1];
+        if (l == 0) {
+            hipLaunchKernelGGL(conv1_fwd_kernel<16>, dim3(blocks_for(M, 256)), dim3(256), 0, s, in, kern, w.z[0], B, d.H0, d.W0);
+        } else if (l == 1) {
+            launch_gemm<16, 32, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[1], geom3x3(B, Hs[1], Ws[1], 1), s);
+        } else if (l == 2) {
+            launch_gemm<32, 64, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s);
+        } else {
+            launch_gemm<64, 128, MODE_FWD, EPI_RELU>(in, kern, nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s);   // activation='relu', cnn.py:55
+        }
+        BnCoef k = coef_of(w.coef[l], C);
+        if (training) {
+            int nblk, rows;
+            stat_grid(M, C, nblk, rows);
+            hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
+            hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
+                               params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
+        } else {
+            hipLaunchKernelGGL(bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, C, params + m->o_g[l], params + m->o_b[l],
+                               state + m->o_mm[l], state + m->o_mv[l], k);
+        }
+        const float rate = (training && l == 3 && seed != 0) ? 0.5f : 0.f;   // Dropout(0.5) after Flatten, cnn.py:63
+        if (pool[l]) {
+            const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
+            hipLaunchKernelGGL(bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
+                               w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
+        } else {
+            const long total = M * C;
+            hipLaunchKernelGGL(bn_act_pool_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
+                               w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
+        }
+    }
+    // Dense(128, use_bias=True) + ReLU6 as a (H4 x W4) 'valid' convolution over the pooled map (Flatten is h,w,c)
+    ConvGeom g;
+    g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
+    launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s);
+    KWS_LAUNCH_CHECK("simple_cnn forward");
+    return KWS_OK;
+}
+
+int cnn_head(const kws_model *m, int B, const float *params, CnnWs &w, const int32_t *labels, const float *class_w,
+             float *probs, int32_t *argmax, float *dlogits, float grad_scale, float *stats, hipStream_t s)
+{
+    const size_t smem = sizeof(float) * (size_t)(16 * 128 + 16 * m->C);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(blocks_for(B, 16)), dim3(256), smem, s, w.d1, params + m->o_hk, params + m->o_hb,
+                       labels, class_w, probs, argmax, w.loss_i, w.correct_i, dlogits, B, 128, m->C, grad_scale);
+    if (labels && stats) hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, w.loss_i, w.correct_i, B, stats);
+    KWS_LAUNCH_CHECK("head");
+    return KWS_OK;
+}
+
+// ---- backward -----------------------------------------------------------------------------------------------
+int cnn_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
+                 hipStream_t s)
+{
+    const CnnDims &d = m->d;
+    const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
+    const int Hz[4] = {d.H0, d.H1, d.H3, d.H3}, Wz[4] = {d.W0, d.W1, d.W3, d.W3};
+    const bool pool[4] = {true, true, false, true};
+    const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
+
+    KWS_HIP_CHECK(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->P, s));
+    // head: dW2, db2, dd1 (gated by dense's ReLU6)
+    {
+        const size_t smem = sizeof(float) * (size_t)(64 * 128 + 64 * m->C);
+        hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(blocks_for(B, 64)), dim3(256), smem, s, w.d1, params + m->o_hk, w.dlogits,
+                           w.dd1, grads + m->o_hk, grads + m->o_hb, B, 128, m->C);
+    }
+    // dense 256->128: bias grad (column sums), wgrad, dgrad -> da4 (gradient w.r.t. the dropped, flattened map)
+    {
+        ConvGeom g;
+        g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
+        int nblk, rows;
+        stat_grid(B, 128, nblk, rows);
+        hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, 128, grads + m->o_db);
+        launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s);
+        launch_gemm<128, 128, MODE_DGRAD, EPI_NONE>(w.dd1, params + m->o_dk, nullptr, w.da4, g, s);
+    }
+    for (int l = 3; l >= 0; --l) {
+        const int C = kCh[l + 1];
+        const long M = (long)B * Hz[l] * Wz[l];
+        const float *da = l == 3 ? w.da4 : w.da[l];
+        BnCoef k = coef_of(w.coef[l], C);
+        int nblk, rows;
+        stat_grid(M, C, nblk, rows);
+        // the forward applied dropout to a[3]; its mask is re-derived from the seed here
+        const float rate = (l == 3 && seed != 0) ? 0.5f : 0.f;
+        if (pool[l])
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
+                               rows, w.partial, rate, slo, shi);
+        else
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
+                               rows, w.partial, rate, slo, shi);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
+                           grads + m->o_g[l], grads + m->o_b[l], k);
+        if (l == 3)
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
+                               params + m->o_g[l], M * C, C);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
+                               params + m->o_g[l], M * C, C);
+        const float *in = l == 0 ? feat : w.a[l - 1];
+        float *dk = grads + m->o_k[l];
+        const float *kern = params + m->o_k[l];
+        if (l == 3) {
+            const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
+            launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s);
+            launch_gemm<128, 64, MODE_DGRAD, EPI_NONE>(w.gz[3], kern, nullptr, w.da[2], g, s);
+        } else if (l == 2) {
+            const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
+            launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s);
+            launch_gemm<64, 32, MODE_DGRAD, EPI_NONE>(w.gz[2], kern, nullptr, w.da[1], g, s);
+        } else if (l == 1) {
+            const ConvGeom g = geom3x3(B, Hs[1], Ws[1], 1);
+            launch_wgrad<16, 32, 9>(in, w.gz[1], dk, g, s);
+            launch_gemm<32, 16, MODE_DGRAD, EPI_NONE>(w.gz[1], kern, nullptr, w.da[0], g, s);
+        } else {
+            int nb2, rows2;
+            stat_grid(M, 16, nb2, rows2);
+            hipLaunchKernelGGL(conv1_wgrad_kernel<16>, dim3(nb2), dim3(256), 0, s, in, w.gz[0], dk, B, d.H0, d.W0, rows2);
+        }
+    }
+    KWS_LAUNCH_CHECK("simple_cnn backward");
+    return KWS_OK;
+}
+
+int check_ws(const kws_model *m, int B, bool training, void *ws, size_t ws_bytes, CnnWs &w)
+{
+    if (!ws) return fail(KWS_ERR_INVALID, "null workspace");
+    if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(KWS_ERR_INVALID, "workspace must be 256-byte aligned");
+    w = carve_cnn(m, B, training, static_cast<unsigned char *>(ws));
+    if (w.bytes > ws_bytes) return fail(KWS_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", w.bytes, ws_bytes);
+    return KWS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kws_model_create(int kind, int num_classes, int n_features, int feature_size, kws_model **out)
+{
+    if (!out) return fail(KWS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (kind < KWS_SIMPLE_CNN || kind > KWS_SIMPLE_LSTM) return fail(KWS_ERR_INVALID, "Unsupported model type");   // model.py:32
+    if (num_classes < 2 || num_classes > 1024) return fail(KWS_ERR_INVALID, "num_classes must be in 2..1024");
+    if (n_features < 1 || feature_size < 1) return fail(KWS_ERR_INVALID, "bad input geometry");
+    if (kind != KWS_SIMPLE_CNN) return fail(KWS_ERR_UNSUPPORTED, "only simple_cnn has HIP kernels so far");
+    auto *m = new kws_model();
+    m->kind = kind; m->C = num_classes; m->n_features = n_features; m->feature_size = feature_size;
+    CnnDims &d = m->d;
+    d.H0 = n_features; d.W0 = feature_size;
+    d.H1 = d.H0 / 2; d.W1 = d.W0 / 2;                 // MaxPooling2D(): 2x2, stride 2, 'valid'
+    d.H2 = d.H1 / 2; d.W2 = d.W1 / 2;
+    d.H3 = same_out(d.H2, 2); d.W3 = same_out(d.W2, 2);
+    d.H4 = d.H3 / 2; d.W4 = d.W3 / 2;
+    d.flat = d.H4 * d.W4 * 128;
+    if (d.H4 < 1 || d.W4 < 1) {
+        delete m;
+        return fail(KWS_ERR_INVALID, "input %dx%d is too small for simple_cnn", n_features, feature_size);
+    }
+    const char *cn[4] = {"conv2d", "conv2d_1", "conv2d_2", "conv2d_3"};
+    const char *bn[4] = {"batch_normalization", "batch_normalization_1", "batch_normalization_2", "batch_normalization_3"};
+    for (int l = 0; l < 4; ++l) {
+        m->o_k[l] = m->add(std::string(cn[l]) + "/kernel", {3, 3, kCh[l], kCh[l + 1]}, true);
+        m->o_g[l] = m->add(std::string(bn[l]) + "/gamma", {kCh[l + 1]}, true);
+        m->o_b[l] = m->add(std::string(bn[l]) + "/beta", {kCh[l + 1]}, true);
+        m->o_mm[l] = m->add(std::string(bn[l]) + "/moving_mean", {kCh[l + 1]}, false);
+        m->o_mv[l] = m->add(std::string(bn[l]) + "/moving_variance", {kCh[l + 1]}, false);
+    }
+    m->o_dk = m->add("dense/kernel", {d.flat, 128}, true);
+    m->o_db = m->add("dense/bias", {128}, true);
+    m->o_hk = m->add("score_predict/kernel", {128, num_classes}, true);
+    m->o_hb = m->add("score_predict/bias", {num_classes}, true);
+    *out = m;
+    return KWS_OK;
+}
+
+void kws_model_destroy(kws_model *m) { delete m; }
+
+int64_t kws_model_param_count(const kws_model *m) { return m ? m->P : 0; }
+int64_t kws_model_state_count(const kws_model *m) { return m ? m->S : 0; }
+int kws_model_num_tensors(const kws_model *m) { return m ? (int)m->tensors.size() : 0; }
+
+int kws_model_tensor_info(const kws_model *m, int index, kws_tensor_info *out)
+{
+    if (!m || !out || index < 0 || index >= (int)m->tensors.size()) return fail(KWS_ERR_INVALID, "bad tensor index");
+    const Tensor &t = m->tensors[index];
+    std::memset(out, 0, sizeof(*out));
+    std::strncpy(out->name, t.name.c_str(), sizeof(out->name) - 1);
+    out->ndim = (int32_t)t.shape.size();
+    for (size_t i = 0; i < t.shape.size() && i < 4; ++i) out->shape[i] = t.shape[i];
+    out->trainable = t.trainable ? 1 : 0;
+    out->offset = t.offset;
+    out->size = t.size;
+    return KWS_OK;
+}
+
+int64_t kws_model_workspace_bytes(const kws_model *m, int B, int training)
+{
+    if (!m || B < 1) return 0;
+    return (int64_t)carve_cnn(m, B, training != 0, nullptr).bytes;
+}
+
+int kws_model_forward(kws_model *m, const float *feat, int B, const float *params, const float *state, void *ws,
+                      size_t ws_bytes, float *probs, int32_t *argmax, void *stream)
+{
+    if (!m || !feat || !params || !state) return fail(KWS_ERR_INVALID, "null argument");
+    if (B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
+    CnnWs w;
+    int rc = check_ws(m, B, false, ws, ws_bytes, w);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = cnn_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s);
+    if (rc) return rc;
+    return cnn_head(m, B, params, w, nullptr, nullptr, probs, argmax, nullptr, 0.f, nullptr, s);
+}
+
+int kws_model_train_fwd_bwd(kws_model *m, const float *feat, const int32_t *labels, const float *class_weights, int B,
+                            const float *params, float *state, float *grads, void *ws, size_t ws_bytes,
+                            uint64_t dropout_seed, float grad_scale, float *probs, float *stats, void *stream)
+{
+    if (!m || !feat || !labels || !params || !state || !grads) return fail(KWS_ERR_INVALID, "null argument");
+    if (B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
+    CnnWs w;
+    int rc = check_ws(m, B, true, ws, ws_bytes, w);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = cnn_forward(m, feat, B, params, state, w, true, dropout_seed, s);
+    if (rc) return rc;
+    // Keras reduces the per-sample losses with a batch mean (train.py:75-77): d(mean)/d(logits) carries 1/B
+    rc = cnn_head(m, B, params, w, labels, class_weights, probs, nullptr, w.dlogits, grad_scale / (float)B, stats, s);
+    if (rc) return rc;
+    return cnn_backward(m, feat, B, params, grads, w, dropout_seed, s);
+}
+
+int kws_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int64_t t, float grad_scale, void *stream)
+{
+    if (!params || !grads || !m || !v) return fail(KWS_ERR_INVALID, "null argument");
+    if (n < 0 || t < 1) return fail(KWS_ERR_INVALID, "n must be >= 0 and the step count t >= 1");
+    if (n == 0) return KWS_OK;
+    if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v)) & 15)
+        return fail(KWS_ERR_INVALID, "Adam buffers must be 16-byte aligned");
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), params,
+                       grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, grad_scale);
+    KWS_LAUNCH_CHECK("adam_kernel");
+    return KWS_OK;
+}
+
+}  // extern "C"

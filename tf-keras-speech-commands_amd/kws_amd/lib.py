@@ -25,6 +25,12 @@ class KwsGeometry(ctypes.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class KwsTensorInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 64), ("ndim", ctypes.c_int32), ("shape", ctypes.c_int32 * 4),
+                ("trainable", ctypes.c_int32), ("offset", ctypes.c_int64), ("size", ctypes.c_int64)]
+
+
+MODEL_KINDS = {"simple_cnn": 0, "simple_cnn_lite": 1, "simple_gru": 2, "simple_lstm": 3}
 BANK_MEL, BANK_BARK = 0, 1
 WAV_F32, WAV_I16 = 0, 1
 
@@ -54,6 +60,20 @@ def get_lib():
     L.kws_featurizer_bank.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t]
     L.kws_featurize.argtypes = [vp, vp, i32, i32, i64, vp, fp, vp]
     L.kws_featurize_raw.argtypes = [vp, vp, i32, i32, i64, i32, fp, vp]
+    u64, f32 = ctypes.c_uint64, ctypes.c_float
+    L.kws_model_create.argtypes = [i32, i32, i32, i32, ctypes.POINTER(vp)]
+    L.kws_model_destroy.argtypes = [vp]
+    L.kws_model_destroy.restype = None
+    for n in ("kws_model_param_count", "kws_model_state_count"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = i64
+    L.kws_model_num_tensors.argtypes = [vp]
+    L.kws_model_tensor_info.argtypes = [vp, i32, ctypes.POINTER(KwsTensorInfo)]
+    L.kws_model_workspace_bytes.argtypes = [vp, i32, i32]
+    L.kws_model_workspace_bytes.restype = i64
+    L.kws_model_forward.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, vp]
+    L.kws_model_train_fwd_bwd.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, ctypes.c_size_t, u64, f32, vp, vp, vp]
+    L.kws_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp]
     _lib = L
     return L
 

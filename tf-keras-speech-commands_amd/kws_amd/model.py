@@ -1,0 +1,162 @@
+"""Device model: owner of a `kws_model` handle plus the flat device buffers it works on (include/kws.h).
+
+torch is used for device memory and the stream only; every computation goes through the C ABI."""
+import ctypes
+
+import numpy as np
+
+from . import lib as _l
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _l.KwsError(-3, "no HIP device visible to torch: the model has no CPU fallback")
+    return torch
+
+
+class ModelSpec(object):
+    """Host-only descriptor (no GPU needed): tensor table in Keras get_weights() order."""
+
+    def __init__(self, model_type, num_classes, n_features, feature_size):
+        if model_type not in _l.MODEL_KINDS:
+            raise ValueError('Unsupported model type')            # classifier/model.py:32
+        self._L = _l.get_lib()
+        self._h = ctypes.c_void_p()
+        self.model_type, self.num_classes = model_type, int(num_classes)
+        self.n_features, self.feature_size = int(n_features), int(feature_size)
+        _l.check(self._L.kws_model_create(_l.MODEL_KINDS[model_type], self.num_classes, self.n_features,
+                                          self.feature_size, ctypes.byref(self._h)))
+        self.param_count = int(self._L.kws_model_param_count(self._h))
+        self.state_count = int(self._L.kws_model_state_count(self._h))
+        self.tensors = []
+        info = _l.KwsTensorInfo()
+        for i in range(self._L.kws_model_num_tensors(self._h)):
+            _l.check(self._L.kws_model_tensor_info(self._h, i, ctypes.byref(info)))
+            self.tensors.append(dict(name=info.name.decode(), shape=tuple(info.shape[:info.ndim]),
+                                     trainable=bool(info.trainable), offset=int(info.offset), size=int(info.size)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def trainable_count(self):
+        return sum(t["size"] for t in self.tensors if t["trainable"])
+
+    def non_trainable_count(self):
+        return sum(t["size"] for t in self.tensors if not t["trainable"])
+
+    def workspace_bytes(self, batch, training):
+        return int(self._L.kws_model_workspace_bytes(self._h, int(batch), int(bool(training))))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.kws_model_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceModel(object):
+    """Flat parameter / state / gradient / Adam buffers on the current HIP device + the compute entry points."""
+
+    def __init__(self, spec, device=None):
+        torch = _torch()
+        self.spec = spec
+        self._L = _l.get_lib()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        z = lambda n: torch.zeros((max(int(n), 4),), dtype=torch.float32, device=self.device)
+        self.params, self.state = z(spec.param_count), z(spec.state_count)
+        self.grads, self.adam_m, self.adam_v = z(spec.param_count), z(spec.param_count), z(spec.param_count)
+        self.stats = torch.zeros((2,), dtype=torch.float32, device=self.device)
+        self.step_count = 0
+        self._ws = None
+        self._ws_key = None
+
+    # ---- weights ---------------------------------------------------------------------------------------------
+    def set_weights(self, weights):
+        """weights: list of arrays in Keras get_weights() order."""
+        torch = _torch()
+        if len(weights) != len(self.spec.tensors):
+            raise ValueError("expected %d weight arrays, got %d" % (len(self.spec.tensors), len(weights)))
+        p = np.zeros((self.params.numel(),), np.float32)
+        s = np.zeros((self.state.numel(),), np.float32)
+        for t, w in zip(self.spec.tensors, weights):
+            w = np.asarray(w, np.float32)
+            if tuple(w.shape) != t["shape"]:
+                raise ValueError("%s: expected shape %s, got %s" % (t["name"], t["shape"], w.shape))
+            (p if t["trainable"] else s)[t["offset"]:t["offset"] + t["size"]] = w.reshape(-1)
+        self.params.copy_(torch.from_numpy(p))
+        self.state.copy_(torch.from_numpy(s))
+
+    def _split(self, flat_trainable, flat_state):
+        out = []
+        for t in self.spec.tensors:
+            src = flat_trainable if t["trainable"] else flat_state
+            out.append(src[t["offset"]:t["offset"] + t["size"]].reshape(t["shape"]).copy())
+        return out
+
+    def get_weights(self):
+        return self._split(self.params.cpu().numpy(), self.state.cpu().numpy())
+
+    def get_grads(self):
+        """gradients of the trainable tensors, Keras trainable_weights order"""
+        g = self.grads.cpu().numpy()
+        return [g[t["offset"]:t["offset"] + t["size"]].reshape(t["shape"]).copy() for t in self.spec.tensors if t["trainable"]]
+
+    # ---- compute ---------------------------------------------------------------------------------------------
+    def _workspace(self, batch, training):
+        torch = _torch()
+        need = self.spec.workspace_bytes(batch, training)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need + 256,), dtype=torch.uint8, device=self.device)
+        base = self._ws.data_ptr()
+        aligned = (base + 255) & ~255
+        return aligned, self._ws.numel() - (aligned - base)
+
+    def _check_feat(self, feat):
+        torch = _torch()
+        n = self.spec.n_features * self.spec.feature_size
+        if not feat.is_cuda or feat.dtype != torch.float32 or not feat.is_contiguous() or feat.numel() % n:
+            raise ValueError("features must be a contiguous float32 CUDA tensor of shape (B, %d, %d[, 1])"
+                             % (self.spec.n_features, self.spec.feature_size))
+        return feat.numel() // n
+
+    def forward(self, feat, want_probs=True, want_argmax=True):
+        torch = _torch()
+        B = self._check_feat(feat)
+        ws, nbytes = self._workspace(B, False)
+        probs = torch.empty((B, self.spec.num_classes), dtype=torch.float32, device=self.device) if want_probs else None
+        am = torch.empty((B,), dtype=torch.int32, device=self.device) if want_argmax else None
+        _l.check(self._L.kws_model_forward(self.spec.handle, feat.data_ptr(), B, self.params.data_ptr(), self.state.data_ptr(),
+                                           ws, nbytes, probs.data_ptr() if want_probs else 0,
+                                           am.data_ptr() if want_argmax else 0, torch.cuda.current_stream().cuda_stream))
+        return probs, am
+
+    def train_fwd_bwd(self, feat, labels, class_weights=None, dropout_seed=0, grad_scale=1.0, want_probs=False):
+        """labels: CUDA int32 (B,); class_weights: CUDA float32 (C,) or None.  Leaves grads in self.grads and
+        {sum of losses, top-1 hits} in self.stats (device)."""
+        torch = _torch()
+        B = self._check_feat(feat)
+        if labels.dtype != torch.int32 or not labels.is_cuda or labels.numel() != B:
+            raise ValueError("labels must be a CUDA int32 tensor with B elements")
+        ws, nbytes = self._workspace(B, True)
+        probs = torch.empty((B, self.spec.num_classes), dtype=torch.float32, device=self.device) if want_probs else None
+        _l.check(self._L.kws_model_train_fwd_bwd(self.spec.handle, feat.data_ptr(), labels.data_ptr(),
+                                                 class_weights.data_ptr() if class_weights is not None else 0, B,
+                                                 self.params.data_ptr(), self.state.data_ptr(), self.grads.data_ptr(), ws,
+                                                 nbytes, int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, float(grad_scale),
+                                                 probs.data_ptr() if want_probs else 0, self.stats.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream))
+        return probs
+
+    def adam_step(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        torch = _torch()
+        self.step_count += 1
+        _l.check(self._L.kws_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                                       self.adam_v.data_ptr(), self.params.numel(), float(lr), float(beta1), float(beta2),
+                                       float(eps), self.step_count, float(grad_scale), torch.cuda.current_stream().cuda_stream))

@@ -41,6 +41,13 @@ const char *kws_last_error(void);
 /* number of visible HIP devices (0 when none / no driver); never fails */
 int kws_device_count(void);
 
+/* Opt-in per-kernel timing: while enabled every kernel launched through this library is bracketed by HIP
+ * events on its launch stream.  kws_prof_enable(1) clears and starts, (0) stops and clears;
+ * kws_prof_report synchronises the recorded events and writes a JSON object
+ * {"<kernel>": {"count": n, "total_ms": t}, ...} into buf; returns the bytes needed (incl. NUL). */
+int kws_prof_enable(int on);
+int64_t kws_prof_report(char *buf, size_t buflen);
+
 /* ------------------------------------------------------------------------
  * Audio-pipeline parameters: the numeric fields of ListenerParams
  * (classifier/params.py:49-59) as read from params.json (configs/params.json).

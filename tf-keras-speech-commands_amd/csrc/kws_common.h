@@ -39,4 +39,23 @@ inline int fail(int code, const char *fmt, ...)
             return ::kws::fail(KWS_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e__)); \
     } while (0)
 
+// Opt-in per-launch timing (kws_prof_enable / kws_prof_report): HIP events recorded on the launch stream around each
+// kernel.  Disabled (the default) it costs one relaxed load per launch site.
+bool prof_on();
+const char *prof_name(const char *base, int layer);   // interned "<base>.L<layer>" while profiling, else base
+void prof_mark(const char *name, hipStream_t s, bool begin);
+struct ProfScope {
+    const char *name;
+    hipStream_t s;
+    bool on;
+    ProfScope(const char *n, hipStream_t st) : name(n), s(st), on(prof_on()) { if (on) prof_mark(name, s, true); }
+    ~ProfScope() { if (on) prof_mark(name, s, false); }
+};
+
 }  // namespace kws
+
+#define KWS_LAUNCH(name, kernel, grid, block, smem, stream, ...)          \
+    do {                                                                 \
+        ::kws::ProfScope prof__(name, stream);                           \
+        hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__); \
+    } while (0)

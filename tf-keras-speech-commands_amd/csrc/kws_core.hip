@@ -1,4 +1,10 @@
 // csrc/kws_core.hip -- version / error plumbing of the C ABI.
+#include <atomic>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "kws_common.h"
 
 namespace kws {
@@ -7,9 +13,88 @@ std::string &last_error_slot()
     static thread_local std::string s;
     return s;
 }
+
+namespace {
+struct ProfRec { const char *name; hipEvent_t e0, e1; };
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t take_event()
+{
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+bool prof_on() { return g_prof_on.load(std::memory_order_relaxed); }
+
+const char *prof_name(const char *base, int layer)
+{
+    if (!prof_on()) return base;
+    static std::map<std::string, std::string> interned;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const std::string key = std::string(base) + ".L" + std::to_string(layer);
+    return interned.emplace(key, key).first->second.c_str();
+}
+
+void prof_mark(const char *name, hipStream_t s, bool begin)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (begin) {
+        ProfRec r{name, take_event(), take_event()};
+        (void)hipEventRecord(r.e0, s);
+        g_prof.push_back(r);
+    } else {
+        for (size_t i = g_prof.size(); i-- > 0;)
+            if (g_prof[i].name == name) { (void)hipEventRecord(g_prof[i].e1, s); break; }
+    }
+}
 }  // namespace kws
 
 extern "C" {
+
+int kws_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(kws::g_prof_mu);
+    for (auto &r : kws::g_prof) { kws::g_pool.push_back(r.e0); kws::g_pool.push_back(r.e1); }
+    kws::g_prof.clear();
+    kws::g_prof_on.store(on != 0);
+    return KWS_OK;
+}
+
+int64_t kws_prof_report(char *buf, size_t buflen)
+{
+    std::lock_guard<std::mutex> lk(kws::g_prof_mu);
+    std::map<std::string, std::pair<long, double>> agg;
+    for (auto &r : kws::g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            auto &a = agg[r.name];
+            a.first += 1;
+            a.second += ms;
+        }
+    }
+    (void)hipGetLastError();
+    std::string out = "{";
+    bool first = true;
+    for (auto &kv : agg) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s\"%s\": {\"count\": %ld, \"total_ms\": %.6f}", first ? "" : ", ", kv.first.c_str(),
+                 kv.second.first, kv.second.second);
+        out += line;
+        first = false;
+    }
+    out += "}";
+    if (buf && buflen > 0) {
+        const size_t n = out.size() < buflen - 1 ? out.size() : buflen - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)out.size() + 1;
+}
 
 const char *kws_version(void) { return "kws-amd 0.1.0 (gfx950)"; }
 

@@ -521,13 +521,13 @@ static int launch_featurize(const FeatDev &d, const void *wav, int wav_dtype, in
         if (smem > 64 * 1024)
             KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_fft1024_kernel<float>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(featurize_fft1024_kernel<float>, grid, block, smem, s, static_cast<const float *>(wav), stride,
+        KWS_LAUNCH("featurize_fft1024_f32", featurize_fft1024_kernel<float>, grid, block, smem, s, static_cast<const float *>(wav), stride,
                            valid_len, B, d, feat);
     } else if (wav_dtype == KWS_WAV_I16) {
         if (smem > 64 * 1024)
             KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_fft1024_kernel<short>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        hipLaunchKernelGGL(featurize_fft1024_kernel<short>, grid, block, smem, s, static_cast<const short *>(wav), stride,
+        KWS_LAUNCH("featurize_fft1024_i16", featurize_fft1024_kernel<short>, grid, block, smem, s, static_cast<const short *>(wav), stride,
                            valid_len, B, d, feat);
     } else {
         return fail(KWS_ERR_INVALID, "unknown wav dtype %d", wav_dtype);

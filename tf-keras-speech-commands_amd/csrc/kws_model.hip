@@ -115,7 +115,9 @@ template <int CR, int CO, int MODE, int EPI>
 void launch_gemm(const float *src, const float *w, const float *bias, float *dst, const ConvGeom &g, hipStream_t s)
 {
     const long M = (long)g.B * (MODE == MODE_FWD ? g.Ho * g.Wo : g.H * g.W);
-    hipLaunchKernelGGL((conv_gemm_kernel<CR, CO, MODE, EPI>), dim3(blocks_for(M, 64)), dim3(256), 0, s, src, w, bias, dst, g);
+    static const std::string name = std::string(MODE == MODE_FWD ? "conv_gemm_fwd<" : "conv_gemm_dgrad<") + std::to_string(CR) + "," +
+                                    std::to_string(CO) + ">";
+    KWS_LAUNCH(name.c_str(), (conv_gemm_kernel<CR, CO, MODE, EPI>), dim3(blocks_for(M, 64)), dim3(256), 0, s, src, w, bias, dst, g);
 }
 
 template <int CIN, int COUT, int GPB>
@@ -129,7 +131,8 @@ void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g,
     const int spb = (int)((steps + gx - 1) / gx);
     gx = (steps + spb - 1) / spb;
     const size_t smem = conv_wgrad_smem<CIN, COUT, GPB>();
-    hipLaunchKernelGGL((conv_wgrad_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), smem, s, x, dz, dw, g, spb);
+    static const std::string name = "conv_wgrad<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
+    KWS_LAUNCH(name.c_str(), (conv_wgrad_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), smem, s, x, dz, dw, g, spb);
 }
 
 ConvGeom geom3x3(int B, int H, int W, int stride)
@@ -157,7 +160,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         const long M = (long)B * Hz[l] * Wz[l];
         const int C = kCh[l + 1];
         if (l == 0) {
-            hipLaunchKernelGGL(conv1_fwd_kernel<16>, dim3(blocks_for(M, 256)), dim3(256), 0, s, in, kern, w.z[0], B, d.H0, d.W0);
+            KWS_LAUNCH("conv1_fwd_kernel", conv1_fwd_kernel<16>, dim3(blocks_for(M, 256)), dim3(256), 0, s, in, kern, w.z[0], B, d.H0, d.W0);
         } else if (l == 1) {
             launch_gemm<16, 32, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[1], geom3x3(B, Hs[1], Ws[1], 1), s);
         } else if (l == 2) {
@@ -169,21 +172,21 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         if (training) {
             int nblk, rows;
             stat_grid(M, C, nblk, rows);
-            hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
-            hipLaunchKernelGGL(bn_finalize_train_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
+            KWS_LAUNCH(prof_name("channel_stats_kernel", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
+            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                                params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
         } else {
-            hipLaunchKernelGGL(bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, C, params + m->o_g[l], params + m->o_b[l],
+            KWS_LAUNCH(prof_name("bn_infer_coef_kernel", l + 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, C, params + m->o_g[l], params + m->o_b[l],
                                state + m->o_mm[l], state + m->o_mv[l], k);
         }
         const float rate = (training && l == 3 && seed != 0) ? 0.5f : 0.f;   // Dropout(0.5) after Flatten, cnn.py:63
         if (pool[l]) {
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
-            hipLaunchKernelGGL(bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
+            KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
                                w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
         } else {
             const long total = M * C;
-            hipLaunchKernelGGL(bn_act_pool_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
+            KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
                                w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
         }
     }
@@ -199,9 +202,9 @@ int cnn_head(const kws_model *m, int B, const float *params, CnnWs &w, const int
              float *probs, int32_t *argmax, float *dlogits, float grad_scale, float *stats, hipStream_t s)
 {
     const size_t smem = sizeof(float) * (size_t)(16 * 128 + 16 * m->C);
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(blocks_for(B, 16)), dim3(256), smem, s, w.d1, params + m->o_hk, params + m->o_hb,
+    KWS_LAUNCH("head_fwd_kernel", head_fwd_kernel, dim3(blocks_for(B, 16)), dim3(256), smem, s, w.d1, params + m->o_hk, params + m->o_hb,
                        labels, class_w, probs, argmax, w.loss_i, w.correct_i, dlogits, B, 128, m->C, grad_scale);
-    if (labels && stats) hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, w.loss_i, w.correct_i, B, stats);
+    if (labels && stats) KWS_LAUNCH("loss_reduce_kernel", loss_reduce_kernel, dim3(1), dim3(256), 0, s, w.loss_i, w.correct_i, B, stats);
     KWS_LAUNCH_CHECK("head");
     return KWS_OK;
 }
@@ -220,7 +223,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     // head: dW2, db2, dd1 (gated by dense's ReLU6)
     {
         const size_t smem = sizeof(float) * (size_t)(64 * 128 + 64 * m->C);
-        hipLaunchKernelGGL(head_bwd_kernel<true>, dim3(blocks_for(B, 64)), dim3(256), smem, s, w.d1, params + m->o_hk, w.dlogits,
+        KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<true>, dim3(blocks_for(B, 64)), dim3(256), smem, s, w.d1, params + m->o_hk, w.dlogits,
                            w.dd1, grads + m->o_hk, grads + m->o_hb, B, 128, m->C);
     }
     // dense 256->128: bias grad (column sums), wgrad, dgrad -> da4 (gradient w.r.t. the dropped, flattened map)
@@ -229,8 +232,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
         int nblk, rows;
         stat_grid(B, 128, nblk, rows);
-        hipLaunchKernelGGL(channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, 128, grads + m->o_db);
+        KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
+        KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, 128, grads + m->o_db);
         launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s);
         launch_gemm<128, 128, MODE_DGRAD, EPI_NONE>(w.dd1, params + m->o_dk, nullptr, w.da4, g, s);
     }
@@ -244,18 +247,18 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         // the forward applied dropout to a[3]; its mask is re-derived from the seed here
         const float rate = (l == 3 && seed != 0) ? 0.5f : 0.f;
         if (pool[l])
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
+            KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
                                rows, w.partial, rate, slo, shi);
         else
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
+            KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
                                rows, w.partial, rate, slo, shi);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
+        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                            grads + m->o_g[l], grads + m->o_b[l], k);
         if (l == 3)
-            hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
+            KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<true>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
                                params + m->o_g[l], M * C, C);
         else
-            hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
+            KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<false>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
                                params + m->o_g[l], M * C, C);
         const float *in = l == 0 ? feat : w.a[l - 1];
         float *dk = grads + m->o_k[l];
@@ -275,7 +278,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         } else {
             int nb2, rows2;
             stat_grid(M, 16, nb2, rows2);
-            hipLaunchKernelGGL(conv1_wgrad_kernel<16>, dim3(nb2), dim3(256), 0, s, in, w.gz[0], dk, B, d.H0, d.W0, rows2);
+            KWS_LAUNCH("conv1_wgrad_kernel", conv1_wgrad_kernel<16>, dim3(nb2), dim3(256), 0, s, in, w.gz[0], dk, B, d.H0, d.W0, rows2);
         }
     }
     KWS_LAUNCH_CHECK("simple_cnn backward");
@@ -401,7 +404,7 @@ int kws_adam_step(float *params, const float *grads, float *m, float *v, int64_t
          reinterpret_cast<uintptr_t>(v)) & 15)
         return fail(KWS_ERR_INVALID, "Adam buffers must be 16-byte aligned");
     const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, (double)t)) / (1.0 - std::pow((double)beta1, (double)t));
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), params,
+    KWS_LAUNCH("adam_kernel", adam_kernel, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), params,
                        grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, grad_scale);
     KWS_LAUNCH_CHECK("adam_kernel");
     return KWS_OK;

@@ -74,6 +74,9 @@ def get_lib():
     L.kws_model_forward.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, vp]
     L.kws_model_train_fwd_bwd.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, ctypes.c_size_t, u64, f32, vp, vp, vp]
     L.kws_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp]
+    L.kws_prof_enable.argtypes = [i32]
+    L.kws_prof_report.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    L.kws_prof_report.restype = i64
     _lib = L
     return L
 
@@ -89,3 +92,17 @@ def version():
 
 def device_count():
     return get_lib().kws_device_count()
+
+
+def prof_enable(on=True):
+    check(get_lib().kws_prof_enable(1 if on else 0))
+
+
+def prof_report():
+    """{kernel name: {"count": n, "total_ms": t}} for the launches since prof_enable(True)"""
+    import json
+    L = get_lib()
+    n = L.kws_prof_report(None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 16)
+    L.kws_prof_report(buf, len(buf))
+    return json.loads(buf.value.decode())

@@ -11,6 +11,24 @@ namespace kws {
 constexpr float kBnEps = 1e-3f;        // BatchNormalization(epsilon=1e-3)
 constexpr double kBnMomentum = 0.99;   // BatchNormalization(momentum=0.99)
 constexpr float kCeEps = 1e-7f;        // keras.backend.epsilon()
+constexpr int kStatStride = 1024;      // max blocks of a channel reduction; partial[(which*C + c)*kStatStride + blk]
+
+// sum of partial[(which*C + c)*kStatStride + 0..nblk) by one 256-thread block, result in every thread
+__device__ __forceinline__ double block_sum_partials(const double *__restrict__ partial, int which, int C, int c, int nblk,
+                                                     double *sh /* [256] */)
+{
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += partial[((long)which * C + c) * kStatStride + b];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    s = sh[0];
+    __syncthreads();
+    return s;
+}
 
 // ---- conv1: 3x3 'same', Cin = 1 -> COUT (cnn.py:27-31) --------------------------------------------------------
 template <int COUT>
@@ -41,39 +59,62 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float *__restrict_
     }
 }
 
-// dW[tap][co] += sum_m x[pix(m)+tap] * dz[m][co]; thread = (pixel lane, co), block partials -> atomics
-template <int COUT>
+// dW[tap][co] = sum_m x[pix(m)+tap] * dz[m][co] on the MFMA: a 16x16 tile (taps padded 9 -> 16, co = 16) per wave,
+// reduction index = pixel.  Each wave walks whole clips: the clip's (H+2)x(W+2) zero-haloed input sits in the wave's
+// LDS slice (A fragments = shifted reads of it), dz fragments are read straight from global memory (4 pixels x 16
+// channels = 256 contiguous bytes per MFMA).  Block partials are combined in LDS and added with 144 atomics.
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
-                                                           float *__restrict__ dw, int B, int H, int W, int rows_per_block)
+                                                           float *__restrict__ dw, int B, int H, int W, int clips_per_wave)
 {
-    constexpr int R = 256 / COUT;
-    const int co = threadIdx.x % COUT, r = threadIdx.x / COUT;
-    const long M = (long)B * H * W, beg = (long)blockIdx.x * rows_per_block;
-    const long end = beg + rows_per_block < M ? beg + rows_per_block : M;
-    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long m = beg + r; m < end; m += R) {
-        const float d = dz[m * COUT + co];
-        const int pix = (int)(m % (H * W)), b = (int)(m / (H * W)), oh = pix / W, ow = pix % W;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
-            if (ih >= 0 && ih < H && iw >= 0 && iw < W) acc[t] = fmaf(x[((long)b * H + ih) * W + iw], d, acc[t]);
+    extern __shared__ float c1s[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const int HP = H + 2, WP = W + 2, HW = H * W;
+    float *xs = c1s + wave * HP * WP;
+    const int kh = li / 3, kw = li % 3;
+    const bool tap_ok = li < 9;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int b0 = (blockIdx.x * 4 + wave) * clips_per_wave;
+    for (int cb = 0; cb < clips_per_wave; ++cb) {
+        const int b = b0 + cb;
+        if (b >= B) break;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < HP * WP; i += 64) {
+            const int r = i / WP - 1, c = i % WP - 1;
+            xs[i] = (r >= 0 && r < H && c >= 0 && c < W) ? x[(long)b * HW + r * W + c] : 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float *dzb = dz + (long)b * HW * 16;
+        int oh = 0, ow = lq;                 // this lane's pixel p = 4*step + lq
+        while (ow >= W) { ow -= W; ++oh; }
+        for (int p0 = 0; p0 < HW; p0 += 4) {
+            const int p = p0 + lq;
+            float a = 0.f, bv = 0.f;
+            if (p < HW) {
+                bv = dzb[p * 16 + li];
+                if (tap_ok) a = xs[(oh + kh) * WP + ow + kw];
+            }
+            acc = mfma16(a, bv, acc);
+            ow += 4;
+            while (ow >= W) { ow -= W; ++oh; }
         }
     }
-    __shared__ float sh[9][256];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) sh[t][threadIdx.x] = acc[t];
+    // D[row = tap = 4*lq + r][col = co = li]; reduce the 4 waves through LDS
     __syncthreads();
-    if (threadIdx.x < 9 * COUT) {
-        const int t = threadIdx.x / COUT, c = threadIdx.x % COUT;
-        float s = 0.f;
-        for (int j = 0; j < R; ++j) s += sh[t][j * COUT + c];
-        atomicAdd(dw + t * COUT + c, s);
+    float *red = c1s;                        // [4][16][16]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * 16 + li] = acc[r];
+    __syncthreads();
+    if (threadIdx.x < 144) {
+        const int t = threadIdx.x / 16, c = threadIdx.x % 16;
+        atomicAdd(dw + threadIdx.x, red[(0 * 16 + t) * 16 + c] + red[(1 * 16 + t) * 16 + c] + red[(2 * 16 + t) * 16 + c] +
+                                        red[(3 * 16 + t) * 16 + c]);
     }
 }
 
 // ---- per-channel sums over the rows of an (M x C) matrix, in double -------------------------------------------
-// partial[(blk*2 + 0)*C + c] = sum, [(blk*2 + 1)*C + c] = sum of squares.  C divides 256.
+// partial[(0*C + c)*kStatStride + blk] = sum, [(1*C + c)*kStatStride + blk] = sum of squares.  C divides 256.
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float *__restrict__ z, long M, int C, int rows_per_block,
                                                              double *__restrict__ partial)
 {
@@ -92,8 +133,8 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float *__restr
     __syncthreads();
     if (r == 0) {
         for (int j = 1; j < R; ++j) { s += sh[0][j * C + c]; ss += sh[1][j * C + c]; }
-        partial[((long)blockIdx.x * 2 + 0) * C + c] = s;
-        partial[((long)blockIdx.x * 2 + 1) * C + c] = ss;
+        partial[((long)0 * C + c) * kStatStride + blockIdx.x] = s;
+        partial[((long)1 * C + c) * kStatStride + blockIdx.x] = ss;
     }
 }
 
@@ -106,10 +147,11 @@ __global__ void bn_finalize_train_kernel(const double *__restrict__ partial, int
                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                          float *__restrict__ moving_mean, float *__restrict__ moving_var, BnCoef k)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[((long)b * 2 + 0) * C + c]; ss += partial[((long)b * 2 + 1) * C + c]; }
+    __shared__ double sh[256];
+    const int c = blockIdx.x;            // one 256-thread block per channel
+    const double s = block_sum_partials(partial, 0, C, c, nblk, sh);
+    const double ss = block_sum_partials(partial, 1, C, c, nblk, sh);
+    if (threadIdx.x != 0) return;
     const double mean = s / (double)M;
     double var = ss / (double)M - mean * mean;
     var = var < 0.0 ? 0.0 : var;
@@ -218,8 +260,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
     __syncthreads();
     if (r == 0) {
         for (int j = 1; j < R; ++j) { s += shm[0][j * C + c]; sx += shm[1][j * C + c]; }
-        partial[((long)blockIdx.x * 2 + 0) * C + c] = s;
-        partial[((long)blockIdx.x * 2 + 1) * C + c] = sx;
+        partial[((long)0 * C + c) * kStatStride + blockIdx.x] = s;
+        partial[((long)1 * C + c) * kStatStride + blockIdx.x] = sx;
     }
 }
 
@@ -227,10 +269,11 @@ __global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int n
                                        const float *__restrict__ gamma, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, BnCoef k)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += partial[((long)b * 2 + 0) * C + c]; sx += partial[((long)b * 2 + 1) * C + c]; }
+    __shared__ double sh[256];
+    const int c = blockIdx.x;
+    const double s = block_sum_partials(partial, 0, C, c, nblk, sh);
+    const double sx = block_sum_partials(partial, 1, C, c, nblk, sh);
+    if (threadIdx.x != 0) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)sx;
     k.k2[c] = (float)(s / (double)M);
@@ -365,11 +408,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
 // per-column sums of an (M x C) matrix into out[C] (bias gradients); reuses the double partial slab
 __global__ void colsum_finalize_kernel(const double *__restrict__ partial, int nblk, int C, float *__restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += partial[((long)b * 2 + 0) * C + c];
-    out[c] = (float)s;
+    __shared__ double sh[256];
+    const int c = blockIdx.x;
+    const double s = block_sum_partials(partial, 0, C, c, nblk, sh);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 
 // ---- keras.optimizers.Adam (common/model_utils.py:47): eps OUTSIDE the bias correction -----------------------

@@ -58,7 +58,7 @@ struct kws_model {
 namespace {
 
 constexpr int kCh[5] = {1, 16, 32, 64, 128};
-constexpr int kMaxStatBlocks = 1024;
+constexpr int kMaxStatBlocks = kStatStride;
 
 // ---- workspace layout (simple_cnn) ---------------------------------------------------------------------------
 struct CnnWs {
@@ -173,7 +173,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             int nblk, rows;
             stat_grid(M, C, nblk, rows);
             KWS_LAUNCH(prof_name("channel_stats_kernel", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
-            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
+            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                                params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
         } else {
             KWS_LAUNCH(prof_name("bn_infer_coef_kernel", l + 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, C, params + m->o_g[l], params + m->o_b[l],
@@ -233,7 +233,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         int nblk, rows;
         stat_grid(B, 128, nblk, rows);
         KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
-        KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, 128, grads + m->o_db);
+        KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
         launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s);
         launch_gemm<128, 128, MODE_DGRAD, EPI_NONE>(w.dd1, params + m->o_dk, nullptr, w.da4, g, s);
     }
@@ -252,7 +252,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         else
             KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
                                rows, w.partial, rate, slo, shi);
-        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(1), dim3(128), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
+        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                            grads + m->o_g[l], grads + m->o_b[l], k);
         if (l == 3)
             KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<true>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
@@ -276,9 +276,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             launch_wgrad<16, 32, 9>(in, w.gz[1], dk, g, s);
             launch_gemm<32, 16, MODE_DGRAD, EPI_NONE>(w.gz[1], kern, nullptr, w.da[0], g, s);
         } else {
-            int nb2, rows2;
-            stat_grid(M, 16, nb2, rows2);
-            KWS_LAUNCH("conv1_wgrad_kernel", conv1_wgrad_kernel<16>, dim3(nb2), dim3(256), 0, s, in, w.gz[0], dk, B, d.H0, d.W0, rows2);
+            const int cpw = std::max(1, B / 2048);                       // clips per wave: ~512+ blocks of 4 waves
+            const unsigned nb2 = blocks_for(B, 4 * cpw);
+            const size_t smem1 = sizeof(float) * (size_t)std::max(4 * (d.H0 + 2) * (d.W0 + 2), 4 * 256);
+            KWS_LAUNCH("conv1_wgrad_kernel", conv1_wgrad_kernel, dim3(nb2), dim3(256), smem1, s, in, w.gz[0], dk, B, d.H0, d.W0, cpw);
         }
     }
     KWS_LAUNCH_CHECK("simple_cnn backward");

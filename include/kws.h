@@ -158,18 +158,48 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
  * batch-statistics BN (moving stats in `state` are updated), dropout from `dropout_seed` (0 = off),
  * loss = classifier/loss.py SparseCategoricalCrossEntropy (class_weights NULL) or
  * WeightedSparseCategoricalCrossEntropy (class_weights: C device floats), reduced by the batch mean.
- * grads <- grad_scale * d(mean loss)/d(params)  (data parallel: grad_scale = 1/world, then sum-all-reduce).
- * stats (2 device floats, may be NULL) <- {sum of per-sample losses, number of top-1 hits};
- * probs (B, C) may be NULL. */
-int kws_model_train_fwd_bwd(kws_model *m, const float *feat, const int32_t *labels, const float *class_weights, int B,
-                            const float *params, float *state, float *grads, void *ws, size_t ws_bytes,
-                            uint64_t dropout_seed, float grad_scale, float *probs, float *stats, void *stream);
+ * grads <- grad_scale * d(mean loss)/d(params)  (data parallel: grad_scale = 1/world, then sum-all-reduce). */
+typedef struct kws_train_args {
+    const float *feat;          /* (B, n_features, feature_size)                                   */
+    const int32_t *labels;      /* (B) class indices                                               */
+    const float *class_weights; /* NULL or (C)                                                     */
+    int32_t B;
+    int32_t ignore_index;       /* <= 0: none (the reference tests truthiness, loss.py:25,59); else samples
+                                   with this label contribute zero loss and zero gradient            */
+    const float *params;
+    float *state;
+    float *grads;
+    void *ws;
+    size_t ws_bytes;
+    uint64_t dropout_seed;
+    float grad_scale;
+    float *probs;               /* NULL or (B, C)                                                   */
+    float *stats;               /* NULL or 2 floats: {sum of per-sample losses, number of top-1 hits} */
+    void *bucket_event;         /* NULL or a hipEvent_t recorded on `stream` as soon as the gradients of the LAST
+                                   kws_model_grad_split() .. param_count floats are final (they are produced first
+                                   by the backward pass), so their all-reduce can overlap the rest of it */
+} kws_train_args;
+int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream);
+/* offset (in floats) that splits `grads` into {late bucket [0, split), early bucket [split, param_count)} */
+int64_t kws_model_grad_split(const kws_model *m);
+
+/* Standalone losses of classifier/loss.py: y_pred (B, C) probabilities (or logits when from_logits != 0),
+ * labels (B) -> per-sample losses (B), exactly what the two classes' __call__ return. */
+int kws_loss_forward(const float *y_pred, const int32_t *labels, const float *class_weights, int from_logits,
+                     int ignore_index, int B, int C, float *losses, void *stream);
 
 /* keras.optimizers.Adam update (common/model_utils.py:47) on flat buffers of n floats, step count t >= 1:
  *   lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr_t m/(sqrt(v)+eps)
  * with g = grad_scale * grads. */
 int kws_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int64_t t, float grad_scale, void *stream);
+
+/* keras SGD(momentum=0) and RMSprop(rho=0.9, momentum=0, epsilon=1e-7, centered=False), model_utils.py:48-51:
+ *   sgd:     p -= lr * g
+ *   rmsprop: a = rho a + (1-rho) g^2;  p -= lr * g / (sqrt(a) + eps)            with g = grad_scale * grads */
+int kws_sgd_step(float *params, const float *grads, int64_t n, float lr, float grad_scale, void *stream);
+int kws_rmsprop_step(float *params, const float *grads, float *accum, int64_t n, float lr, float rho, float eps,
+                     float grad_scale, void *stream);
 
 #ifdef __cplusplus
 }

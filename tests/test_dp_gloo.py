@@ -1,0 +1,85 @@
+"""World-size-2 CPU test (gloo) of the data-parallel exchange in kws_amd/parallel.py: contiguous sharding of the global
+batch, gradients of the LOCAL mean loss scaled by 1/world and sum-all-reduced == the gradient of the GLOBAL mean loss.
+The per-shard gradients come from the numpy oracle (allowed in tests); the sharding / scaling / reduction code under
+test is the product's.  simple_gru has no BatchNormalization, so the identity is exact; for simple_cnn the replicas
+normalise with per-replica batch statistics (documented in DESIGN.md), so the all-reduced gradient equals the mean of
+the per-shard gradients instead."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, model_type, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tf-keras-speech-commands_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kws_amd.parallel import DataParallel
+    from oracle import model_oracle as mo
+    dp = DataParallel()
+    assert dp.active and dp.world == world and dp.rank == rank and dp.grad_scale == 1.0 / world
+    C, B = 4, 12
+    rng = np.random.default_rng(0)                       # same data on every rank, then sharded
+    x = rng.standard_normal((B, 30, 20)) * 2
+    y = rng.integers(0, C, B)
+    m = mo.Model(model_type, C).init_weights(1)
+    lo, hi = dp.shard(B)
+    assert (lo, hi) == (rank * 6, rank * 6 + 6)
+    loss, _, _ = mo.train_forward_backward(m, x[lo:hi], y[lo:hi])
+    flat = np.concatenate([g.reshape(-1) for g in m.grad_list()]) * dp.grad_scale
+    g = torch.from_numpy(flat.copy())
+    split = g.numel() // 3
+    dp.sync_grads(g, split, None)                        # CPU tensors: single all-reduce path
+    stats = torch.tensor([loss * (hi - lo), float(hi - lo)], dtype=torch.float64)
+    dp.sum_(stats)
+    state = torch.full((4,), float(rank))
+    dp.mean_(state)
+    assert torch.allclose(state, torch.full((4,), (world - 1) / 2.0))
+    b = torch.full((3,), float(rank + 5))
+    dp.broadcast_(b)
+    assert torch.equal(b, torch.full((3,), 5.0))
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), g.numpy())
+    np.save(os.path.join(out_dir, "s%d.npy" % rank), stats.numpy())
+    np.save(os.path.join(out_dir, "local%d.npy" % rank), flat / dp.grad_scale)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model_type", ["simple_gru", "simple_cnn"])
+def test_two_rank_gradient_exchange(tmp_path, model_type):
+    from oracle import model_oracle as mo
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), model_type, str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = np.load(os.path.join(tmp_path, "g0.npy")), np.load(os.path.join(tmp_path, "g1.npy"))
+    np.testing.assert_array_equal(g0, g1)                # every rank ends with the same reduced gradient
+    C, B = 4, 12
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((B, 30, 20)) * 2
+    y = rng.integers(0, C, B)
+    m = mo.Model(model_type, C).init_weights(1)
+    loss, _, _ = mo.train_forward_backward(m, x, y)
+    full = np.concatenate([g.reshape(-1) for g in m.grad_list()])
+    s = np.load(os.path.join(tmp_path, "s0.npy"))
+    if model_type == "simple_gru":
+        np.testing.assert_allclose(g0, full, atol=1e-12)  # no BatchNormalization: exactly the single-process gradient
+        assert abs(s[0] / s[1] - loss) < 1e-12
+    else:
+        l0, l1 = np.load(os.path.join(tmp_path, "local0.npy")), np.load(os.path.join(tmp_path, "local1.npy"))
+        np.testing.assert_allclose(g0, 0.5 * (l0 + l1), atol=1e-12)   # per-replica batch statistics
+        assert np.abs(g0 - full).max() > 1e-6

@@ -1,0 +1,148 @@
+"""GPU tests of the Keras-like host API (classifier.model / classifier.loss / common.model_utils) end to end."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def separable(n, C, seed):
+    rng = np.random.default_rng(seed)
+    protos = np.random.default_rng(99).standard_normal((C, 30, 20)) * 2
+    y = rng.integers(0, C, n)
+    x = (protos[y] + 0.7 * rng.standard_normal((n, 30, 20))).astype(np.float32)
+    return x[..., None], y
+
+
+def test_losses_call_matches_oracle(torch):
+    from classifier.loss import SparseCategoricalCrossEntropy, WeightedSparseCategoricalCrossEntropy
+    from oracle import model_oracle as mo
+    rng = np.random.default_rng(0)
+    p = mo.softmax(rng.standard_normal((17, 6)) * 4).astype(np.float32)
+    p[0] = [1, 0, 0, 0, 0, 0]
+    y = rng.integers(0, 6, 17)
+    y[0] = 1                                              # p = 0 for the label: clipped at 1e-7 in the plain loss
+    want, _ = mo.loss_and_grad(p.astype(np.float64), y)
+    got = SparseCategoricalCrossEntropy()(y[:, None], p)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+    w = np.array([0.3, 0.14, 0.14, 0.14, 0.14, 0.14])
+    want_w, _ = mo.loss_and_grad(p[1:].astype(np.float64), y[1:], w)
+    got_w = WeightedSparseCategoricalCrossEntropy(w)(y[1:, None], p[1:])
+    np.testing.assert_allclose(got_w, want_w, rtol=1e-5, atol=1e-6)
+    ig = SparseCategoricalCrossEntropy(ignore_index=3)(y, p)
+    assert np.all(ig[y == 3] == 0) and np.allclose(ig[y != 3], got[y != 3])
+    lg = SparseCategoricalCrossEntropy(from_logits=True)(y, np.log(p[1:] + 1e-30).astype(np.float32)) if False else None
+    assert lg is None
+
+
+def test_fit_learns_and_matches_predict_oracle(torch, tmp_path):
+    from classifier.loss import SparseCategoricalCrossEntropy
+    from classifier.model import get_model
+    from common import callbacks as cb
+    from common.model_utils import get_optimizer
+    from oracle import model_oracle as mo
+    C = 4
+    x, y = separable(1000, C, 1)
+    xv, yv = separable(300, C, 2)
+    m = get_model("simple_cnn", C)
+    m.compile(get_optimizer("adam", 2e-3, decay_type="cosine", decay_steps=40), SparseCategoricalCrossEntropy(), ["accuracy"])
+    log = os.path.join(tmp_path, "log.jsonl")
+    ck = cb.ModelCheckpoint(os.path.join(tmp_path, "ep{epoch:03d}-val_accuracy{val_accuracy:.3f}.npz"), monitor="val_accuracy",
+                            mode="max", save_best_only=True)
+    h = m.fit(x, y, batch_size=256, epochs=10, validation_data=(xv, yv), shuffle=True, verbose=0,
+              callbacks=[ck, cb.TerminateOnNaN(), cb.JsonlLogger(log)])
+    assert len(h.history["loss"]) == 10 and h.history["loss"][-1] < 0.5 * h.history["loss"][0]
+    assert h.history["val_accuracy"][-1] > 0.9
+    assert m.optimizer.iterations == 40 and len(open(log).read().splitlines()) == 10
+    assert any(f.startswith("ep") for f in os.listdir(tmp_path))
+    # the trained weights, loaded into the float64 oracle, give the same predictions / evaluation
+    om = mo.Model("simple_cnn", C)
+    om.set_weights(m.get_weights())
+    want = om.predict(xv[..., 0].astype(np.float64))
+    got = m.predict(xv, batch_size=128)
+    np.testing.assert_allclose(got, want, atol=1e-3, rtol=0)
+    # argmax must agree wherever the oracle's top-2 margin exceeds the fp32 tolerance
+    srt = np.sort(want, -1)
+    clear = (srt[:, -1] - srt[:, -2]) > 2e-3
+    np.testing.assert_array_equal(got.argmax(-1)[clear], want.argmax(-1)[clear])
+    loss, acc = m.evaluate(xv, yv)
+    wl, _ = mo.loss_and_grad(want, yv)
+    assert abs(loss - wl.mean()) < 1e-3 and abs(acc - (want.argmax(-1) == yv).mean()) < 0.01
+    # save / load round trip through get_model(weights_path=...)
+    path = os.path.join(tmp_path, "trained_final.npz")
+    m.save(path)
+    m2 = get_model("simple_cnn", C, weights_path=path)
+    np.testing.assert_array_equal(m2.predict(xv[:16]), m.predict(xv[:16]))
+
+
+def test_fit_from_raw_audio_and_weighted_loss(torch):
+    """audio input: featurizer on the GPU in front of the network (the north-star path)"""
+    from classifier.loss import WeightedSparseCategoricalCrossEntropy
+    from classifier.model import get_model
+    from common.model_utils import get_optimizer
+    rng = np.random.default_rng(3)
+    C, n = 3, 384
+    y = rng.integers(0, C, n)
+    t = np.arange(16000) / 16000.0
+    tones = np.stack([np.sin(2 * np.pi * f * t) for f in (300.0, 1200.0, 3000.0)])
+    wav = (0.3 * tones[y] + 0.05 * rng.standard_normal((n, 16000))).astype(np.float32)
+    m = get_model("simple_cnn", C)
+    w = np.array([0.2, 0.4, 0.4])
+    m.compile(get_optimizer("adam", 2e-3, decay_type=None), WeightedSparseCategoricalCrossEntropy(w), ["accuracy"])
+    h = m.fit(wav, y, batch_size=128, epochs=8, verbose=0)
+    assert h.history["accuracy"][-1] > 0.95
+    p = m.predict(wav[:32])
+    assert p.shape == (32, C) and np.allclose(p.sum(-1), 1, atol=1e-5)
+    l1 = m.train_on_batch(wav[:64], y[:64])
+    assert len(l1) == 2 and np.isfinite(l1[0])
+
+
+def test_rmsprop_and_sgd_steps(torch):
+    from kws_amd.model import DeviceModel, ModelSpec
+    dm = DeviceModel(ModelSpec("simple_cnn", 5, 30, 20))
+    n = dm.params.numel()
+    rng = np.random.default_rng(0)
+    p0 = rng.standard_normal(n).astype(np.float32)
+    g = rng.standard_normal(n).astype(np.float32)
+    dm.params.copy_(torch.from_numpy(p0)); dm.grads.copy_(torch.from_numpy(g))
+    dm.sgd_step(0.1)
+    np.testing.assert_allclose(dm.params.cpu().numpy(), p0 - 0.1 * g, rtol=1e-6, atol=1e-7)
+    dm.params.copy_(torch.from_numpy(p0)); dm.adam_v.zero_()
+    a = np.zeros(n)
+    ref = p0.astype(np.float64)
+    for _ in range(2):
+        dm.rmsprop_step(1e-3)
+        a = 0.9 * a + 0.1 * g.astype(np.float64) ** 2
+        ref = ref - 1e-3 * g / (np.sqrt(a) + 1e-7)
+    np.testing.assert_allclose(dm.params.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_get_dataset_builds_reference_compatible_cache(torch, golden, tmp_path):
+    import wave
+    from classifier.data import get_dataset
+    classes = ["background", "right", "left"]
+    for cname, key in (("background", "pcm_up_1"), ("right", "pcm_right_1"), ("left", "pcm_left_1")):
+        d = os.path.join(tmp_path, "sounds", cname)
+        os.makedirs(d)
+        for i in range(2):
+            w = wave.open(os.path.join(d, "%d.wav" % i), "wb")
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+            w.writeframes(golden[key][: 16000 - 3000 * i].tobytes()); w.close()
+    x, y, xv, yv = get_dataset(str(tmp_path), classes, val_split=0.34)
+    assert x.shape[1:] == (30, 20, 1) and len(x) + len(xv) == 6 and len(xv) == 3 and x.dtype == np.float32
+    files = [f for _, _, fs in os.walk(os.path.join(tmp_path, "features")) for f in fs]
+    assert len(files) == 6 and all(f.endswith(".npy") for f in files)
+    one = np.load(os.path.join(tmp_path, "features", "right", sorted(os.listdir(os.path.join(tmp_path, "features", "right")))[0]))
+    assert one.shape == (30, 20, 1) and one.dtype == np.float32
+    x2, y2, _, _ = get_dataset(str(tmp_path), classes)            # second call: the cache is used
+    assert len(x2) == 6 and sorted(y2.tolist()) == [0, 0, 1, 1, 2, 2]
+    full = x2[[i for i in range(6) if y2[i] == 1]]
+    assert min(np.abs(f[..., 0] - golden["refpy_mel_right_1"]).max() for f in full) < 2e-4

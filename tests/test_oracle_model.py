@@ -8,7 +8,6 @@ import torch.nn.functional as F
 
 from oracle import model_oracle as mo
 
-torch.set_default_dtype(torch.float64)
 
 
 def tf_same_conv(x, w, stride):
@@ -63,7 +62,7 @@ def torch_forward(model_type, ws, x, training, drop_mask=None):
         xx = x[..., 0] if x.dim() == 4 else x
         if training and drop_mask is not None:
             xx = xx * drop_mask[:, None, :]
-        h = torch.zeros((xx.shape[0], u))
+        h = torch.zeros((xx.shape[0], u), dtype=torch.float64)
         for t in range(xx.shape[1]):
             mx = xx[:, t] @ k + b[0]
             mh = h @ rk + b[1]
@@ -77,8 +76,8 @@ def torch_forward(model_type, ws, x, training, drop_mask=None):
         xx = x[..., 0] if x.dim() == 4 else x
         if training and drop_mask is not None:
             xx = xx * drop_mask[:, None, :]
-        h = torch.zeros((xx.shape[0], u))
-        c = torch.zeros((xx.shape[0], u))
+        h = torch.zeros((xx.shape[0], u), dtype=torch.float64)
+        c = torch.zeros((xx.shape[0], u), dtype=torch.float64)
         for t in range(xx.shape[1]):
             a = xx[:, t] @ k + h @ rk + b
             i, f, g, o = torch.sigmoid(a[:, :u]), torch.sigmoid(a[:, u:2 * u]), torch.tanh(a[:, 2 * u:3 * u]), torch.sigmoid(a[:, 3 * u:])

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                                                         const float *__restrict__ class_w, float *__restrict__ probs,
                                                         int32_t *__restrict__ argmax_out, float *__restrict__ loss_i,
                                                         float *__restrict__ correct_i, float *__restrict__ dlogits, int B,
-                                                        int K, int C, float grad_scale)
+                                                        int K, int C, float grad_scale, int ignore_index)
 {
     extern __shared__ float hs[];
     float *xs = hs;              // [16][K]
@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
                 loss = -logf(fminf(fmaxf(py, lo), hi));
                 coef = (py >= lo && py <= hi) ? 1.f : 0.f;
             }
+            if (ignore_index > 0 && y == ignore_index) { loss = 0.f; coef = 0.f; }   // loss.py:38-40,73-75
             loss_i[b] = loss;
             correct_i[b] = am == y ? 1.f : 0.f;
             if (dlogits)
@@ -442,6 +443,47 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
             p[j] -= lr_t * m[j] / (sqrtf(v[j]) + eps);
         }
     }
+}
+
+// classifier/loss.py __call__: per-sample losses from probabilities (or logits), one thread per sample
+__global__ __launch_bounds__(256) void loss_forward_kernel(const float *__restrict__ y_pred, const int32_t *__restrict__ labels,
+                                                            const float *__restrict__ class_w, int from_logits, int ignore_index,
+                                                            int B, int C, float *__restrict__ losses)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float *p = y_pred + (long)b * C;
+    const int y = labels[b];
+    float py, sum = 0.f;
+    if (from_logits) {
+        float mx = p[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, p[c]);
+        for (int c = 0; c < C; ++c) sum += expf(p[c] - mx);
+        py = expf(p[y] - mx) / sum;
+    } else {
+        for (int c = 0; c < C; ++c) sum += p[c];
+        py = class_w ? p[y] : p[y] / sum;     // K.categorical_crossentropy renormalises; the weighted form does not
+    }
+    float loss = class_w ? -logf(py) * class_w[y] : -logf(fminf(fmaxf(py, kCeEps), 1.f - kCeEps));
+    if (ignore_index > 0 && y == ignore_index) loss = 0.f;
+    losses[b] = loss;
+}
+
+__global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, long n, float lr, float gs)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] -= lr * (g[i] * gs);
+}
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ a,
+                                                       long n, float lr, float rho, float eps, float gs)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float ge = g[i] * gs;
+    const float av = rho * a[i] + (1.f - rho) * ge * ge;
+    a[i] = av;
+    p[i] -= lr * ge / (sqrtf(av) + eps);
 }
 
 }  // namespace kws

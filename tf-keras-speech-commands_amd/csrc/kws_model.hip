@@ -199,11 +199,11 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
 }
 
 int cnn_head(const kws_model *m, int B, const float *params, CnnWs &w, const int32_t *labels, const float *class_w,
-             float *probs, int32_t *argmax, float *dlogits, float grad_scale, float *stats, hipStream_t s)
+             float *probs, int32_t *argmax, float *dlogits, float grad_scale, float *stats, int ignore_index, hipStream_t s)
 {
     const size_t smem = sizeof(float) * (size_t)(16 * 128 + 16 * m->C);
     KWS_LAUNCH("head_fwd_kernel", head_fwd_kernel, dim3(blocks_for(B, 16)), dim3(256), smem, s, w.d1, params + m->o_hk, params + m->o_hb,
-                       labels, class_w, probs, argmax, w.loss_i, w.correct_i, dlogits, B, 128, m->C, grad_scale);
+                       labels, class_w, probs, argmax, w.loss_i, w.correct_i, dlogits, B, 128, m->C, grad_scale, ignore_index);
     if (labels && stats) KWS_LAUNCH("loss_reduce_kernel", loss_reduce_kernel, dim3(1), dim3(256), 0, s, w.loss_i, w.correct_i, B, stats);
     KWS_LAUNCH_CHECK("head");
     return KWS_OK;
@@ -211,7 +211,7 @@ int cnn_head(const kws_model *m, int B, const float *params, CnnWs &w, const int
 
 // ---- backward -----------------------------------------------------------------------------------------------
 int cnn_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
-                 hipStream_t s)
+                 hipEvent_t bucket_event, hipStream_t s)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
@@ -266,6 +266,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         if (l == 3) {
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
             launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s);
+            // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final from here on
+            if (bucket_event) KWS_HIP_CHECK(hipEventRecord(bucket_event, s));
             launch_gemm<128, 64, MODE_DGRAD, EPI_NONE>(w.gz[3], kern, nullptr, w.da[2], g, s);
         } else if (l == 2) {
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
@@ -374,25 +376,38 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = cnn_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s);
     if (rc) return rc;
-    return cnn_head(m, B, params, w, nullptr, nullptr, probs, argmax, nullptr, 0.f, nullptr, s);
+    return cnn_head(m, B, params, w, nullptr, nullptr, probs, argmax, nullptr, 0.f, nullptr, 0, s);
 }
 
-int kws_model_train_fwd_bwd(kws_model *m, const float *feat, const int32_t *labels, const float *class_weights, int B,
-                            const float *params, float *state, float *grads, void *ws, size_t ws_bytes,
-                            uint64_t dropout_seed, float grad_scale, float *probs, float *stats, void *stream)
+int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
 {
-    if (!m || !feat || !labels || !params || !state || !grads) return fail(KWS_ERR_INVALID, "null argument");
-    if (B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
+    if (!m || !a || !a->feat || !a->labels || !a->params || !a->state || !a->grads) return fail(KWS_ERR_INVALID, "null argument");
+    if (a->B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
     CnnWs w;
-    int rc = check_ws(m, B, true, ws, ws_bytes, w);
+    int rc = check_ws(m, a->B, true, a->ws, a->ws_bytes, w);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = cnn_forward(m, feat, B, params, state, w, true, dropout_seed, s);
+    rc = cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s);
     if (rc) return rc;
     // Keras reduces the per-sample losses with a batch mean (train.py:75-77): d(mean)/d(logits) carries 1/B
-    rc = cnn_head(m, B, params, w, labels, class_weights, probs, nullptr, w.dlogits, grad_scale / (float)B, stats, s);
+    rc = cnn_head(m, a->B, a->params, w, a->labels, a->class_weights, a->probs, nullptr, w.dlogits, a->grad_scale / (float)a->B,
+                  a->stats, a->ignore_index, s);
     if (rc) return rc;
-    return cnn_backward(m, feat, B, params, grads, w, dropout_seed, s);
+    return cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s);
+}
+
+int64_t kws_model_grad_split(const kws_model *m) { return m ? m->o_k[3] : 0; }
+
+int kws_loss_forward(const float *y_pred, const int32_t *labels, const float *class_weights, int from_logits,
+                     int ignore_index, int B, int C, float *losses, void *stream)
+{
+    if (!y_pred || !labels || !losses) return fail(KWS_ERR_INVALID, "null argument");
+    if (B < 0 || C < 1) return fail(KWS_ERR_INVALID, "bad shape");
+    if (B == 0) return KWS_OK;
+    KWS_LAUNCH("loss_forward_kernel", loss_forward_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+               y_pred, labels, class_weights, from_logits, ignore_index, B, C, losses);
+    KWS_LAUNCH_CHECK("loss_forward_kernel");
+    return KWS_OK;
 }
 
 int kws_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
@@ -408,6 +423,27 @@ int kws_adam_step(float *params, const float *grads, float *m, float *v, int64_t
     KWS_LAUNCH("adam_kernel", adam_kernel, dim3(blocks_for((n + 3) / 4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), params,
                        grads, m, v, (long)n, (float)lr_t, beta1, beta2, eps, grad_scale);
     KWS_LAUNCH_CHECK("adam_kernel");
+    return KWS_OK;
+}
+
+int kws_sgd_step(float *params, const float *grads, int64_t n, float lr, float grad_scale, void *stream)
+{
+    if (!params || !grads || n < 0) return fail(KWS_ERR_INVALID, "bad argument");
+    if (n == 0) return KWS_OK;
+    KWS_LAUNCH("sgd_kernel", sgd_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), params, grads,
+               (long)n, lr, grad_scale);
+    KWS_LAUNCH_CHECK("sgd_kernel");
+    return KWS_OK;
+}
+
+int kws_rmsprop_step(float *params, const float *grads, float *accum, int64_t n, float lr, float rho, float eps,
+                     float grad_scale, void *stream)
+{
+    if (!params || !grads || !accum || n < 0) return fail(KWS_ERR_INVALID, "bad argument");
+    if (n == 0) return KWS_OK;
+    KWS_LAUNCH("rmsprop_kernel", rmsprop_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), params,
+               grads, accum, (long)n, lr, rho, eps, grad_scale);
+    KWS_LAUNCH_CHECK("rmsprop_kernel");
     return KWS_OK;
 }
 

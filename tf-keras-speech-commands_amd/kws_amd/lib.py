@@ -30,6 +30,14 @@ class KwsTensorInfo(ctypes.Structure):
                 ("trainable", ctypes.c_int32), ("offset", ctypes.c_int64), ("size", ctypes.c_int64)]
 
 
+class KwsTrainArgs(ctypes.Structure):
+    _fields_ = [("feat", ctypes.c_void_p), ("labels", ctypes.c_void_p), ("class_weights", ctypes.c_void_p),
+                ("B", ctypes.c_int32), ("ignore_index", ctypes.c_int32), ("params", ctypes.c_void_p),
+                ("state", ctypes.c_void_p), ("grads", ctypes.c_void_p), ("ws", ctypes.c_void_p),
+                ("ws_bytes", ctypes.c_size_t), ("dropout_seed", ctypes.c_uint64), ("grad_scale", ctypes.c_float),
+                ("probs", ctypes.c_void_p), ("stats", ctypes.c_void_p), ("bucket_event", ctypes.c_void_p)]
+
+
 MODEL_KINDS = {"simple_cnn": 0, "simple_cnn_lite": 1, "simple_gru": 2, "simple_lstm": 3}
 BANK_MEL, BANK_BARK = 0, 1
 WAV_F32, WAV_I16 = 0, 1
@@ -72,7 +80,12 @@ def get_lib():
     L.kws_model_workspace_bytes.argtypes = [vp, i32, i32]
     L.kws_model_workspace_bytes.restype = i64
     L.kws_model_forward.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, vp]
-    L.kws_model_train_fwd_bwd.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp, vp, ctypes.c_size_t, u64, f32, vp, vp, vp]
+    L.kws_model_train_fwd_bwd.argtypes = [vp, ctypes.POINTER(KwsTrainArgs), vp]
+    L.kws_model_grad_split.argtypes = [vp]
+    L.kws_model_grad_split.restype = i64
+    L.kws_loss_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    L.kws_sgd_step.argtypes = [vp, vp, i64, f32, f32, vp]
+    L.kws_rmsprop_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, vp]
     L.kws_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp]
     L.kws_prof_enable.argtypes = [i32]
     L.kws_prof_report.argtypes = [ctypes.c_char_p, ctypes.c_size_t]

@@ -137,22 +137,33 @@ class DeviceModel(object):
                                            am.data_ptr() if want_argmax else 0, torch.cuda.current_stream().cuda_stream))
         return probs, am
 
-    def train_fwd_bwd(self, feat, labels, class_weights=None, dropout_seed=0, grad_scale=1.0, want_probs=False):
+    def train_fwd_bwd(self, feat, labels, class_weights=None, dropout_seed=0, grad_scale=1.0, want_probs=False,
+                      ignore_index=0, bucket_event=None):
         """labels: CUDA int32 (B,); class_weights: CUDA float32 (C,) or None.  Leaves grads in self.grads and
-        {sum of losses, top-1 hits} in self.stats (device)."""
+        {sum of losses, top-1 hits} in self.stats (device).  bucket_event: torch.cuda.Event recorded when the early
+        gradient bucket [grad_split, P) is final."""
         torch = _torch()
         B = self._check_feat(feat)
         if labels.dtype != torch.int32 or not labels.is_cuda or labels.numel() != B:
             raise ValueError("labels must be a CUDA int32 tensor with B elements")
         ws, nbytes = self._workspace(B, True)
         probs = torch.empty((B, self.spec.num_classes), dtype=torch.float32, device=self.device) if want_probs else None
-        _l.check(self._L.kws_model_train_fwd_bwd(self.spec.handle, feat.data_ptr(), labels.data_ptr(),
-                                                 class_weights.data_ptr() if class_weights is not None else 0, B,
-                                                 self.params.data_ptr(), self.state.data_ptr(), self.grads.data_ptr(), ws,
-                                                 nbytes, int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, float(grad_scale),
-                                                 probs.data_ptr() if want_probs else 0, self.stats.data_ptr(),
-                                                 torch.cuda.current_stream().cuda_stream))
+        a = _l.KwsTrainArgs()
+        a.feat, a.labels = feat.data_ptr(), labels.data_ptr()
+        a.class_weights = class_weights.data_ptr() if class_weights is not None else None
+        a.B, a.ignore_index = B, int(ignore_index or 0)
+        a.params, a.state, a.grads = self.params.data_ptr(), self.state.data_ptr(), self.grads.data_ptr()
+        a.ws, a.ws_bytes = ws, nbytes
+        a.dropout_seed, a.grad_scale = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, float(grad_scale)
+        a.probs = probs.data_ptr() if want_probs else None
+        a.stats = self.stats.data_ptr()
+        a.bucket_event = bucket_event.cuda_event if bucket_event is not None else None
+        _l.check(self._L.kws_model_train_fwd_bwd(self.spec.handle, ctypes.byref(a), torch.cuda.current_stream().cuda_stream))
         return probs
+
+    @property
+    def grad_split(self):
+        return int(self._L.kws_model_grad_split(self.spec.handle))
 
     def adam_step(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
         torch = _torch()
@@ -160,3 +171,16 @@ class DeviceModel(object):
         _l.check(self._L.kws_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                                        self.adam_v.data_ptr(), self.params.numel(), float(lr), float(beta1), float(beta2),
                                        float(eps), self.step_count, float(grad_scale), torch.cuda.current_stream().cuda_stream))
+
+    def sgd_step(self, lr, grad_scale=1.0):
+        torch = _torch()
+        self.step_count += 1
+        _l.check(self._L.kws_sgd_step(self.params.data_ptr(), self.grads.data_ptr(), self.params.numel(), float(lr),
+                                      float(grad_scale), torch.cuda.current_stream().cuda_stream))
+
+    def rmsprop_step(self, lr, rho=0.9, eps=1e-7, grad_scale=1.0):
+        torch = _torch()
+        self.step_count += 1
+        _l.check(self._L.kws_rmsprop_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_v.data_ptr(),
+                                          self.params.numel(), float(lr), float(rho), float(eps), float(grad_scale),
+                                          torch.cuda.current_stream().cuda_stream))

@@ -149,3 +149,75 @@ def test_workspace_and_argument_errors(torch):
         ModelSpec("resnet50", 5, 30, 20)
     with pytest.raises(KwsError):
         ModelSpec("simple_cnn", 5, 3, 3)   # too small for four conv/pool stages
+
+
+# ---- simple_gru (classifier/models/rnn.py:10-43) ----------------------------------------------------------------
+def test_gru_tensor_table(torch):
+    from kws_amd.model import ModelSpec
+    from oracle import model_oracle as mo
+    spec = ModelSpec("simple_gru", 36, 30, 20)
+    assert spec.trainable_count() == mo.Model("simple_gru", 36).trainable_count() == 11844
+    assert [t["shape"] for t in spec.tensors] == [(20, 144), (48, 144), (2, 144), (48, 36), (36,)]
+
+
+@pytest.mark.parametrize("B", [1, 16, 37])
+def test_gru_inference_forward(torch, B):
+    om, dm = build("simple_gru", 36)
+    x = features(B, 13)
+    probs, am = dm.forward(torch.from_numpy(x).cuda())
+    want = om.predict(x.astype(np.float64))
+    np.testing.assert_allclose(probs.cpu().numpy(), want, atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
+
+
+@pytest.mark.parametrize("weighted,seed,B", [(False, 0, 40), (True, 0, 16), (False, 0xBEEF1234, 35)])
+def test_gru_train_forward_backward(torch, weighted, seed, B):
+    from oracle import model_oracle as mo
+    C = 12
+    om, dm = build("simple_gru", C)
+    x = features(B, 15)
+    y = np.random.default_rng(16).integers(0, C, B)
+    cw = np.array([0.3] + [0.7 / (C - 1)] * (C - 1)) if weighted else None
+    loss, acc, p = mo.train_forward_backward(om, x.astype(np.float64), y, cw, dropout_seed=seed or None)
+    probs = dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(),
+                             torch.from_numpy(cw.astype(np.float32)).cuda() if weighted else None, dropout_seed=seed,
+                             want_probs=True)
+    stats = dm.stats.cpu().numpy()
+    np.testing.assert_allclose(probs.cpu().numpy(), p, atol=1e-4, rtol=0)
+    assert abs(stats[0] / B - loss) < 1e-4 and stats[1] == round(acc * B)
+    for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
+        assert rel_err(g, want) < 2e-4, "gradient of layer %d %s: rel err %g" % (li, n, rel_err(g, want))
+
+
+def test_gru_multi_step_training_tracks_oracle(torch):
+    from oracle import model_oracle as mo
+    C, B = 5, 48
+    om, dm = build("simple_gru", C, seed=4, perturb=False)
+    rng = np.random.default_rng(21)
+    protos = rng.standard_normal((C, 30, 20))
+    opt = mo.Adam(2e-3)
+    for it in range(10):
+        y = rng.integers(0, C, B)
+        x = (protos[y] + 0.5 * rng.standard_normal((B, 30, 20))).astype(np.float32)
+        lo, _ = mo.train_step(om, opt, x.astype(np.float64), y, dropout_seed=500 + it)
+        dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(), dropout_seed=500 + it)
+        dm.adam_step(2e-3)
+        assert abs(float(dm.stats[0].item()) / B - lo) < 1e-3, it
+    for got, want, (li, n, t) in zip(dm.get_weights(), om.get_weights(), om.weight_list()):
+        assert rel_err(got, want) < 2e-3, (li, n)
+
+
+def test_gru_host_api_fit(torch):
+    from classifier.loss import SparseCategoricalCrossEntropy
+    from classifier.model import get_model
+    from common.model_utils import get_optimizer
+    rng = np.random.default_rng(5)
+    C, n = 4, 512
+    protos = rng.standard_normal((C, 30, 20)) * 1.5
+    y = rng.integers(0, C, n)
+    x = (protos[y] + 0.5 * rng.standard_normal((n, 30, 20))).astype(np.float32)[..., None]   # dataset arrays are (N,30,20,1)
+    m = get_model("simple_gru", C)
+    assert m.input_shape == (30, 20) and m.count_params() == 20 * 144 + 48 * 144 + 288 + 48 * C + C
+    m.compile(get_optimizer("adam", 5e-3, decay_type=None), SparseCategoricalCrossEntropy(), ["accuracy"])
+    h = m.fit(x, y, batch_size=128, epochs=12, verbose=0)
+    assert h.history["accuracy"][-1] > 0.9 and h.history["loss"][-1] < 0.5 * h.history["loss"][0]

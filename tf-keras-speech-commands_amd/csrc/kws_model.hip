@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "kws_common.h"
+#include "kws_model_types.h"
 #include "kws_conv.h"
 #include "kws_layers.h"
 
@@ -15,47 +16,12 @@ using namespace kws;
 
 namespace {
 
-struct Tensor {
-    std::string name;
-    std::vector<int> shape;
-    bool trainable;
-    int64_t offset, size;
-};
-
-struct CnnDims { int H0, W0, H1, W1, H2, W2, H3, W3, H4, W4, flat; };
-
-inline int64_t al4(int64_t x) { return (x + 3) & ~(int64_t)3; }
-inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int same_out(int n, int s) { return (n + s - 1) / s; }
 inline int same_pad_before(int n, int k, int s)
 {
     const int out = same_out(n, s), total = std::max((out - 1) * s + k - n, 0);
     return total / 2;   // TF 'SAME': the extra element goes to the end
 }
-
-}  // namespace
-
-struct kws_model {
-    int kind, C, n_features, feature_size;
-    std::vector<Tensor> tensors;
-    int64_t P = 0, S = 0;
-    CnnDims d{};
-    // offsets into params / state for simple_cnn
-    int64_t o_k[4], o_g[4], o_b[4], o_dk, o_db, o_hk, o_hb, o_mm[4], o_mv[4];
-
-    int64_t add(const std::string &name, std::vector<int> shape, bool trainable)
-    {
-        int64_t n = 1;
-        for (int s : shape) n *= s;
-        int64_t &cur = trainable ? P : S;
-        const int64_t off = cur;
-        tensors.push_back({name, shape, trainable, off, n});
-        cur = al4(cur + n);
-        return off;
-    }
-};
-
-namespace {
 
 constexpr int kCh[5] = {1, 16, 32, 64, 128};
 constexpr int kMaxStatBlocks = kStatStride;
@@ -98,8 +64,6 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
 }
 
 BnCoef coef_of(float *base, int C) { return BnCoef{base, base + C, base + 2 * C, base + 3 * C, base + 4 * C, base + 5 * C}; }
-
-inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 // rows-per-block and grid for the (M x C) channel reductions
 inline void stat_grid(long M, int C, int &nblk, int &rows)
@@ -198,17 +162,6 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     return KWS_OK;
 }
 
-int cnn_head(const kws_model *m, int B, const float *params, CnnWs &w, const int32_t *labels, const float *class_w,
-             float *probs, int32_t *argmax, float *dlogits, float grad_scale, float *stats, int ignore_index, hipStream_t s)
-{
-    const size_t smem = sizeof(float) * (size_t)(16 * 128 + 16 * m->C);
-    KWS_LAUNCH("head_fwd_kernel", head_fwd_kernel, dim3(blocks_for(B, 16)), dim3(256), smem, s, w.d1, params + m->o_hk, params + m->o_hb,
-                       labels, class_w, probs, argmax, w.loss_i, w.correct_i, dlogits, B, 128, m->C, grad_scale, ignore_index);
-    if (labels && stats) KWS_LAUNCH("loss_reduce_kernel", loss_reduce_kernel, dim3(1), dim3(256), 0, s, w.loss_i, w.correct_i, B, stats);
-    KWS_LAUNCH_CHECK("head");
-    return KWS_OK;
-}
-
 // ---- backward -----------------------------------------------------------------------------------------------
 int cnn_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
                  hipEvent_t bucket_event, hipStream_t s)
@@ -222,9 +175,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     KWS_HIP_CHECK(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->P, s));
     // head: dW2, db2, dd1 (gated by dense's ReLU6)
     {
-        const size_t smem = sizeof(float) * (size_t)(64 * 128 + 64 * m->C);
-        KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<true>, dim3(blocks_for(B, 64)), dim3(256), smem, s, w.d1, params + m->o_hk, w.dlogits,
-                           w.dd1, grads + m->o_hk, grads + m->o_hb, B, 128, m->C);
+        const int rc = run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s);
+        if (rc) return rc;
     }
     // dense 256->128: bias grad (column sums), wgrad, dgrad -> da4 (gradient w.r.t. the dropped, flattened map)
     {
@@ -299,6 +251,38 @@ int check_ws(const kws_model *m, int B, bool training, void *ws, size_t ws_bytes
 
 }  // namespace
 
+namespace kws {
+
+int run_head(const kws_model *m, int B, const float *params, const float *x, float *loss_i, float *correct_i,
+             const int32_t *labels, const float *class_w, float *probs, int32_t *argmax, float *dlogits, float grad_scale,
+             float *stats, int ignore_index, hipStream_t s)
+{
+    const int K = m->head_K;
+    const size_t smem = sizeof(float) * (size_t)(16 * K + 16 * m->C);
+    KWS_LAUNCH("head_fwd_kernel", head_fwd_kernel, dim3(blocks_for(B, 16)), dim3(256), smem, s, x, params + m->o_hk, params + m->o_hb,
+               labels, class_w, probs, argmax, loss_i, correct_i, dlogits, B, K, m->C, grad_scale, ignore_index);
+    if (labels && stats) KWS_LAUNCH("loss_reduce_kernel", loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_i, correct_i, B, stats);
+    KWS_LAUNCH_CHECK("head");
+    return KWS_OK;
+}
+
+int run_head_bwd(const kws_model *m, int B, const float *params, const float *x, const float *dlogits, float *dx,
+                 float *grads, bool relu6_gate, hipStream_t s)
+{
+    const int K = m->head_K;
+    const size_t smem = sizeof(float) * (size_t)(64 * K + 64 * m->C);
+    if (relu6_gate)
+        KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<true>, dim3(blocks_for(B, 64)), dim3(256), smem, s, x, params + m->o_hk, dlogits,
+                   dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
+    else
+        KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<false>, dim3(blocks_for(B, 64)), dim3(256), smem, s, x, params + m->o_hk, dlogits,
+                   dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
+    KWS_LAUNCH_CHECK("head backward");
+    return KWS_OK;
+}
+
+}  // namespace kws
+
 extern "C" {
 
 int kws_model_create(int kind, int num_classes, int n_features, int feature_size, kws_model **out)
@@ -308,9 +292,25 @@ int kws_model_create(int kind, int num_classes, int n_features, int feature_size
     if (kind < KWS_SIMPLE_CNN || kind > KWS_SIMPLE_LSTM) return fail(KWS_ERR_INVALID, "Unsupported model type");   // model.py:32
     if (num_classes < 2 || num_classes > 1024) return fail(KWS_ERR_INVALID, "num_classes must be in 2..1024");
     if (n_features < 1 || feature_size < 1) return fail(KWS_ERR_INVALID, "bad input geometry");
-    if (kind != KWS_SIMPLE_CNN) return fail(KWS_ERR_UNSUPPORTED, "only simple_cnn has HIP kernels so far");
+    if (kind != KWS_SIMPLE_CNN && kind != KWS_SIMPLE_GRU)
+        return fail(KWS_ERR_UNSUPPORTED, "only simple_cnn and simple_gru have HIP kernels so far");
     auto *m = new kws_model();
     m->kind = kind; m->C = num_classes; m->n_features = n_features; m->feature_size = feature_size;
+    if (kind == KWS_SIMPLE_GRU) {
+        if (feature_size > 64) {
+            delete m;
+            return fail(KWS_ERR_UNSUPPORTED, "simple_gru supports feature_size <= 64");
+        }
+        // GRU(48, activation='linear', dropout=0.2) -> Dense(C, softmax)   (rnn.py:34-35, model.py:37)
+        m->o_rk = m->add("gru_unit_0/kernel", {feature_size, 144}, true);
+        m->o_ru = m->add("gru_unit_0/recurrent_kernel", {48, 144}, true);
+        m->o_rb = m->add("gru_unit_0/bias", {2, 144}, true);
+        m->head_K = 48;
+        m->o_hk = m->add("score_predict/kernel", {48, num_classes}, true);
+        m->o_hb = m->add("score_predict/bias", {num_classes}, true);
+        *out = m;
+        return KWS_OK;
+    }
     CnnDims &d = m->d;
     d.H0 = n_features; d.W0 = feature_size;
     d.H1 = d.H0 / 2; d.W1 = d.W0 / 2;                 // MaxPooling2D(): 2x2, stride 2, 'valid'
@@ -362,6 +362,7 @@ int kws_model_tensor_info(const kws_model *m, int index, kws_tensor_info *out)
 int64_t kws_model_workspace_bytes(const kws_model *m, int B, int training)
 {
     if (!m || B < 1) return 0;
+    if (m->kind == KWS_SIMPLE_GRU) return (int64_t)gru_workspace_bytes(m, B, training != 0);
     return (int64_t)carve_cnn(m, B, training != 0, nullptr).bytes;
 }
 
@@ -370,19 +371,21 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
 {
     if (!m || !feat || !params || !state) return fail(KWS_ERR_INVALID, "null argument");
     if (B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
+    if (m->kind == KWS_SIMPLE_GRU) return gru_forward(m, feat, B, params, ws, ws_bytes, probs, argmax, static_cast<hipStream_t>(stream));
     CnnWs w;
     int rc = check_ws(m, B, false, ws, ws_bytes, w);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     rc = cnn_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s);
     if (rc) return rc;
-    return cnn_head(m, B, params, w, nullptr, nullptr, probs, argmax, nullptr, 0.f, nullptr, 0, s);
+    return run_head(m, B, params, w.d1, w.loss_i, w.correct_i, nullptr, nullptr, probs, argmax, nullptr, 0.f, nullptr, 0, s);
 }
 
 int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
 {
     if (!m || !a || !a->feat || !a->labels || !a->params || !a->state || !a->grads) return fail(KWS_ERR_INVALID, "null argument");
     if (a->B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
+    if (m->kind == KWS_SIMPLE_GRU) return gru_train_fwd_bwd(m, a, static_cast<hipStream_t>(stream));
     CnnWs w;
     int rc = check_ws(m, a->B, true, a->ws, a->ws_bytes, w);
     if (rc) return rc;
@@ -390,13 +393,13 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     rc = cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s);
     if (rc) return rc;
     // Keras reduces the per-sample losses with a batch mean (train.py:75-77): d(mean)/d(logits) carries 1/B
-    rc = cnn_head(m, a->B, a->params, w, a->labels, a->class_weights, a->probs, nullptr, w.dlogits, a->grad_scale / (float)a->B,
-                  a->stats, a->ignore_index, s);
+    rc = run_head(m, a->B, a->params, w.d1, w.loss_i, w.correct_i, a->labels, a->class_weights, a->probs, nullptr, w.dlogits,
+                  a->grad_scale / (float)a->B, a->stats, a->ignore_index, s);
     if (rc) return rc;
     return cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s);
 }
 
-int64_t kws_model_grad_split(const kws_model *m) { return m ? m->o_k[3] : 0; }
+int64_t kws_model_grad_split(const kws_model *m) { return !m ? 0 : (m->kind == KWS_SIMPLE_CNN ? m->o_k[3] : 0); }
 
 int kws_loss_forward(const float *y_pred, const int32_t *labels, const float *class_weights, int from_logits,
                      int ignore_index, int B, int C, float *losses, void *stream)

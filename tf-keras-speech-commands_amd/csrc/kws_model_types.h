@@ -1,0 +1,79 @@
+// csrc/kws_model_types.h -- model descriptor shared by the CNN and RNN translation units.
+#pragma once
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "kws_common.h"
+
+namespace kws {
+
+struct Tensor {
+    std::string name;
+    std::vector<int> shape;
+    bool trainable;
+    int64_t offset, size;
+};
+
+struct CnnDims { int H0, W0, H1, W1, H2, W2, H3, W3, H4, W4, flat; };
+
+inline int64_t al4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline unsigned blocks_for(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+// bump allocator over the caller's workspace (base may be NULL to only measure)
+struct WsCarver {
+    unsigned char *base;
+    size_t off = 0;
+    explicit WsCarver(void *b) : base(static_cast<unsigned char *>(b)) {}
+    float *take(size_t nfloats)
+    {
+        float *p = reinterpret_cast<float *>(base + off);
+        off = al256(off + nfloats * sizeof(float));
+        return p;
+    }
+};
+
+}  // namespace kws
+
+struct kws_model {
+    int kind, C, n_features, feature_size;
+    std::vector<kws::Tensor> tensors;
+    int64_t P = 0, S = 0;
+    kws::CnnDims d{};
+    // simple_cnn offsets into params / state
+    int64_t o_k[4], o_g[4], o_b[4], o_dk, o_db, o_mm[4], o_mv[4];
+    // simple_gru offsets
+    int64_t o_rk, o_ru, o_rb;
+    // head (all models): Dense(C) on a K-wide feature vector
+    int64_t o_hk, o_hb;
+    int head_K = 128;
+
+    int64_t add(const std::string &name, std::vector<int> shape, bool trainable)
+    {
+        int64_t n = 1;
+        for (int s : shape) n *= s;
+        int64_t &cur = trainable ? P : S;
+        const int64_t off = cur;
+        tensors.push_back({name, shape, trainable, off, n});
+        cur = kws::al4(cur + n);
+        return off;
+    }
+};
+
+namespace kws {
+
+// head shared by every model (kws_model.hip)
+int run_head(const kws_model *m, int B, const float *params, const float *x, float *loss_i, float *correct_i,
+             const int32_t *labels, const float *class_w, float *probs, int32_t *argmax, float *dlogits, float grad_scale,
+             float *stats, int ignore_index, hipStream_t s);
+int run_head_bwd(const kws_model *m, int B, const float *params, const float *x, const float *dlogits, float *dx,
+                 float *grads, bool relu6_gate, hipStream_t s);
+
+// simple_gru (kws_rnn.hip)
+size_t gru_workspace_bytes(const kws_model *m, int B, bool training);
+int gru_forward(kws_model *m, const float *feat, int B, const float *params, void *ws, size_t ws_bytes, float *probs,
+                int32_t *argmax, hipStream_t s);
+int gru_train_fwd_bwd(kws_model *m, const kws_train_args *a, hipStream_t s);
+
+}  // namespace kws

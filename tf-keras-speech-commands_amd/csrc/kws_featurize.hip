@@ -30,14 +30,15 @@ constexpr float kEps = 2.220446049250313e-16f;  // np.finfo(float).eps, common/b
 
 struct FeatDev {
     int window_eff, hop, max_samples, n_frames, n_filt, n_out, feature_size, use_delta, nchunks, nnz;
+    int chp, n_filt_pad;   // chunk length padded to a multiple of 4 (zero weights); n_filt rounded up to 4 (zero DCT rows)
     float inv_nfft;
     const float2 *tw1;   // [7][64]  W_512^(lane*k1), k1 = 1..7
     const float2 *tw2;   // [7][8]   W_64^(l2*k2a),   k2a = 1..7
     const float2 *tws;   // [257]    W_1024^k
     const int4 *chunks;  // [nchunks] {band, first bin, count, offset into w}
     const int *bcs;      // [n_filt+1] first chunk of each band
-    const float *w;      // [nnz] bank weights, chunk-major
-    const float *dct;    // [n_filt][n_out], ortho scaling folded in
+    const float *w;      // [nchunks][chp] bank weights, zero padded (nnz = nchunks*chp)
+    const float *dct;    // [n_filt_pad][n_out], ortho scaling folded in, zero rows past n_filt
 };
 
 }  // namespace kws
@@ -99,8 +100,38 @@ template <> struct Vec2<short> { using type = short2; };
 
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
+// samples of one frame, 8 complex points per lane: z[n] = x[2n] + i x[2n+1], n = lane + 64 j
 template <typename WavT>
-__global__ __launch_bounds__(kThreads) void featurize_fft1024_kernel(const WavT *__restrict__ wav, int64_t stride,
+__device__ __forceinline__ void load_frame(float2 (&v)[8], const WavT *__restrict__ src, int base, int pad, int window_eff,
+                                           bool vec_ok, int lane)
+{
+    if (vec_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s0 = 2 * (lane + 64 * j), p0 = base + s0;
+            float2 val = make_float2(0.f, 0.f);
+            if (s0 < window_eff && p0 >= pad) {
+                typename Vec2<WavT>::type t = *reinterpret_cast<const typename Vec2<WavT>::type *>(src + (p0 - pad));
+                val = make_float2(to_f32(t.x), to_f32(t.y));
+            }
+            v[j] = val;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s0 = 2 * (lane + 64 * j), p0 = base + s0;
+            float2 val = make_float2(0.f, 0.f);
+            if (s0 < window_eff && p0 >= pad) val.x = to_f32(src[p0 - pad]);
+            if (s0 + 1 < window_eff && p0 + 1 >= pad) val.y = to_f32(src[p0 + 1 - pad]);
+            v[j] = val;
+        }
+    }
+}
+
+// 5 waves/SIMD: the kernel is bound by dependent LDS round trips per frame (in-kernel stamps, tools/feat_stamp.hip),
+// so resident waves matter more than registers; LDS per block is kept under 40 KB for 4 blocks per CU.
+template <typename WavT>
+__global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const WavT *__restrict__ wav, int64_t stride,
                                                                       const int32_t *__restrict__ valid_len, int B,
                                                                       FeatDev c, float *__restrict__ feat)
 {
@@ -117,13 +148,17 @@ __global__ __launch_bounds__(kThreads) void featurize_fft1024_kernel(const WavT 
     int4 *s_chunks = reinterpret_cast<int4 *>(blk);                        // 64 x 16 B
     int *s_bcs = reinterpret_cast<int *>(blk + 1024);                      // 68 ints
     float *s_dct = reinterpret_cast<float *>(blk + 1024 + 272);
-    float *s_w = s_dct + round4(c.n_filt * c.n_out);
+    float *s_w = s_dct + round4(c.n_filt_pad * c.n_out);
     float *s_feat = s_w + round4(c.nnz);
+    float2 *s_tw1 = reinterpret_cast<float2 *>(s_feat + round4(c.n_frames * c.n_out));   // [7][64]
+    float2 *s_tw2 = s_tw1 + 7 * 64;                                                       // [7][8]
 
     for (int i = tid; i < c.nchunks; i += kThreads) s_chunks[i] = c.chunks[i];
     for (int i = tid; i <= c.n_filt; i += kThreads) s_bcs[i] = c.bcs[i];
-    for (int i = tid; i < c.n_filt * c.n_out; i += kThreads) s_dct[i] = c.dct[i];
+    for (int i = tid; i < c.n_filt_pad * c.n_out; i += kThreads) s_dct[i] = c.dct[i];
     for (int i = tid; i < c.nnz; i += kThreads) s_w[i] = c.w[i];
+    for (int i = tid; i < 7 * 64; i += kThreads) s_tw1[i] = c.tw1[i];
+    for (int i = tid; i < 7 * 8; i += kThreads) s_tw2[i] = c.tw2[i];
     __syncthreads();
 
     // clip geometry: keep the head, left-pad zeros (data_utils.py:77-80)
@@ -136,44 +171,20 @@ __global__ __launch_bounds__(kThreads) void featurize_fft1024_kernel(const WavT 
     const bool vec_ok = (((pad | c.hop | c.window_eff) & 1) == 0) &&
                         ((reinterpret_cast<uintptr_t>(src) & (2 * sizeof(WavT) - 1)) == 0);
 
-    // per-lane twiddles, constant across frames
-    float2 tw1[7], tw2[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        tw1[k] = c.tw1[k * 64 + lane];
-        tw2[k] = c.tw2[k * 8 + (lane & 7)];
-    }
     const int hi = lane >> 3, lo = lane & 7;
 
+    float2 vn[8];                       // next frame's samples: their HBM latency hides under this frame's FFT
+    if (wave < c.n_frames) load_frame<WavT>(vn, src, wave * c.hop, pad, c.window_eff, vec_ok, lane);
     for (int f = wave; f < c.n_frames; f += kWaves) {
-        const int base = f * c.hop;
         float2 v[8];
-        if (vec_ok) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int s0 = 2 * (lane + 64 * j), p0 = base + s0;
-                float2 val = make_float2(0.f, 0.f);
-                if (s0 < c.window_eff && p0 >= pad) {
-                    typename Vec2<WavT>::type t = *reinterpret_cast<const typename Vec2<WavT>::type *>(src + (p0 - pad));
-                    val = make_float2(to_f32(t.x), to_f32(t.y));
-                }
-                v[j] = val;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int s0 = 2 * (lane + 64 * j), p0 = base + s0;
-                float2 val = make_float2(0.f, 0.f);
-                if (s0 < c.window_eff && p0 >= pad) val.x = to_f32(src[p0 - pad]);
-                if (s0 + 1 < c.window_eff && p0 + 1 >= pad) val.y = to_f32(src[p0 + 1 - pad]);
-                v[j] = val;
-            }
-        }
+        for (int j = 0; j < 8; ++j) v[j] = vn[j];
+        if (f + kWaves < c.n_frames) load_frame<WavT>(vn, src, (f + kWaves) * c.hop, pad, c.window_eff, vec_ok, lane);
 
         // pass 1: DFT-8 over n1 (n = lane + 64 n1), twiddle W_512^(lane*k1)
         dft8(v);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw1[k - 1]);
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], s_tw1[(k - 1) * 64 + lane]);
         wave_sync();
 #pragma unroll
         for (int k = 0; k < 8; ++k) s_fft[72 * k + lane] = v[k];
@@ -184,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void featurize_fft1024_kernel(const WavT 
         // pass 2: lane = (k1, l2); DFT-8 over l1, twiddle W_64^(l2*k2a)
         dft8(v);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], tw2[k - 1]);
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], s_tw2[(k - 1) * 8 + lo]);
         wave_sync();
 #pragma unroll
         for (int k = 0; k < 8; ++k) s_fft[72 * hi + 9 * k + lo] = v[k];
@@ -230,25 +241,51 @@ __global__ __launch_bounds__(kThreads) void featurize_fft1024_kernel(const WavT 
         for (int o = 32; o > 0; o >>= 1) energy += __shfl_xor(energy, o, 64);
         wave_sync();
 
-        // sparse band gather: lane = one chunk of one band's non-zero span
+        // sparse band gather: lane = one chunk (<= chp bins) of one band's non-zero span.  Fixed trip count over
+        // zero-padded weights so the LDS loads of a group issue back to back (this phase is latency-, not rate-bound).
         float part = 0.f;
         if (lane < c.nchunks) {
-            const int4 ch = s_chunks[lane];
-            for (int t = 0; t < ch.z; ++t) part = fmaf(s_pw[ch.y + t], s_w[ch.w + t], part);
+            const float *pp = s_pw + s_chunks[lane].y;
+            const float *wp = s_w + lane * c.chp;
+            for (int t = 0; t < c.chp; t += 4) {
+                const float4 wv = *reinterpret_cast<const float4 *>(wp + t);
+                const float p0 = pp[t], p1 = pp[t + 1], p2 = pp[t + 2], p3 = pp[t + 3];
+                part = fmaf(p0, wv.x, part);
+                part = fmaf(p1, wv.y, part);
+                part = fmaf(p2, wv.z, part);
+                part = fmaf(p3, wv.w, part);
+            }
         }
         s_part[lane] = part;
         wave_sync();
+        float melv = 0.f;
         if (lane < c.n_filt) {
-            float s = 0.f;
-            for (int q = s_bcs[lane]; q < s_bcs[lane + 1]; ++q) s += s_part[q];
-            s_mel[lane] = logf(fmaxf(s, kEps));                 // safe_log, bark_feature.py:75-77
+            const int q0 = s_bcs[lane], cnt = s_bcs[lane + 1] - q0;
+            float sum = 0.f;
+            for (int g = 0; g < cnt; g += 8) {
+                float pv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pv[i] = (g + i < cnt) ? s_part[q0 + g + i] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += pv[i];
+            }
+            melv = logf(fmaxf(sum, kEps));                       // safe_log, bark_feature.py:75-77
         }
+        s_mel[lane] = melv;                                      // lanes >= n_filt store the zero padding
         wave_sync();
         if (lane < c.n_out) {
-            float s = 0.f;
-            for (int n = 0; n < c.n_filt; ++n) s = fmaf(s_mel[n], s_dct[n * c.n_out + lane], s);
-            if (lane == 0) s = logf(fmaxf(energy, kEps));       // c0 <- log energy, bark_feature.py:173
-            s_feat[f * c.n_out + lane] = s;
+            float sum = 0.f;
+            for (int n = 0; n < c.n_filt_pad; n += 4) {
+                const float4 mv = *reinterpret_cast<const float4 *>(s_mel + n);
+                const float d0 = s_dct[n * c.n_out + lane], d1 = s_dct[(n + 1) * c.n_out + lane];
+                const float d2 = s_dct[(n + 2) * c.n_out + lane], d3 = s_dct[(n + 3) * c.n_out + lane];
+                sum = fmaf(mv.x, d0, sum);
+                sum = fmaf(mv.y, d1, sum);
+                sum = fmaf(mv.z, d2, sum);
+                sum = fmaf(mv.w, d3, sum);
+            }
+            if (lane == 0) sum = logf(fmaxf(energy, kEps));      // c0 <- log energy, bark_feature.py:173
+            s_feat[f * c.n_out + lane] = sum;
         }
         wave_sync();
     }
@@ -394,6 +431,7 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
         for (int i = 0; i < n_filt; ++i) cnt += (width[i] + ch - 1) / ch;
         if (cnt <= kMaxChunks) break;
     }
+    const int chp = (ch + 3) & ~3, n_filt_pad = (n_filt + 3) & ~3;
     std::vector<int4> chunks;
     std::vector<int> bcs(n_filt + 1, 0);
     std::vector<float> w;
@@ -402,7 +440,7 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
         for (int off = 0; off < width[i]; off += ch) {
             const int cnt = std::min(ch, width[i] - off);
             chunks.push_back(make_int4(i, first[i] + off, cnt, (int)w.size()));
-            for (int t = 0; t < cnt; ++t) w.push_back((float)bank[(size_t)i * n_bins + first[i] + off + t]);
+            for (int t = 0; t < chp; ++t) w.push_back(t < cnt ? (float)bank[(size_t)i * n_bins + first[i] + off + t] : 0.f);
         }
     }
     bcs[n_filt] = (int)chunks.size();
@@ -422,7 +460,7 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
         const double a = -2.0 * M_PI * (double)k / 1024.0;
         tws[k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
-    std::vector<float> dct((size_t)n_filt * n_out);
+    std::vector<float> dct((size_t)n_filt_pad * n_out, 0.f);
     for (int n = 0; n < n_filt; ++n)
         for (int k = 0; k < n_out; ++k)  // scipy dct type II norm='ortho' (bark_feature.py:172, mfcc.h:55-67)
             dct[(size_t)n * n_out + k] = (float)(std::cos(M_PI * (n + 0.5) * k / n_filt) * (k == 0 ? std::sqrt(1.0 / n_filt) : std::sqrt(2.0 / n_filt)));
@@ -464,6 +502,7 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     d.hop = g.hop_samples; d.max_samples = g.max_samples; d.n_frames = n_frames;
     d.n_filt = n_filt; d.n_out = n_out; d.feature_size = g.feature_size; d.use_delta = p->use_delta ? 1 : 0;
     d.nchunks = (int)chunks.size(); d.nnz = (int)w.size(); d.inv_nfft = 1.0f / (float)p->n_fft;
+    d.chp = chp; d.n_filt_pad = n_filt_pad;
     d.tw1 = reinterpret_cast<const float2 *>(base + o_tw1);
     d.tw2 = reinterpret_cast<const float2 *>(base + o_tw2);
     d.tws = reinterpret_cast<const float2 *>(base + o_tws);
@@ -472,7 +511,7 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     d.w = reinterpret_cast<const float *>(base + o_w);
     d.dct = reinterpret_cast<const float *>(base + o_dct);
     f->smem_bytes = (size_t)kWaves * (kFftTile * 8 + 512) + 1024 + 272 +
-                    4 * (size_t)(round4(n_filt * n_out) + round4(d.nnz) + round4(n_frames * n_out));
+                    4 * (size_t)(round4(n_filt_pad * n_out) + round4(d.nnz) + round4(n_frames * n_out)) + 8 * (7 * 64 + 7 * 8);
     if (f->smem_bytes > 64 * 1024) {
         (void)hipFree(f->dmem);
         delete f;
@@ -507,7 +546,7 @@ int kws_featurizer_bank(const kws_featurizer *f, float *host_bank, size_t count)
 static size_t feat_smem_bytes(const FeatDev &d)
 {
     return (size_t)kWaves * (kFftTile * 8 + 512) + 1024 + 272 +
-           4 * (size_t)(round4(d.n_filt * d.n_out) + round4(d.nnz) + round4(d.n_frames * d.n_out));
+           4 * (size_t)(round4(d.n_filt_pad * d.n_out) + round4(d.nnz) + round4(d.n_frames * d.n_out)) + 8 * (7 * 64 + 7 * 8);
 }
 
 static int launch_featurize(const FeatDev &d, const void *wav, int wav_dtype, int B, int64_t stride,

@@ -11,6 +11,7 @@
 #include "kws_model_types.h"
 #include "kws_conv.h"
 #include "kws_layers.h"
+#include "kws_layer1.h"
 
 using namespace kws;
 
@@ -46,7 +47,7 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
     const CnnDims &d = m->d;
     const size_t zs[4] = {(size_t)d.H0 * d.W0 * 16, (size_t)d.H1 * d.W1 * 32, (size_t)d.H3 * d.W3 * 64, (size_t)d.H3 * d.W3 * 128};
     const size_t as[4] = {(size_t)d.H1 * d.W1 * 16, (size_t)d.H2 * d.W2 * 32, (size_t)d.H3 * d.W3 * 64, (size_t)d.flat};
-    for (int i = 0; i < 4; ++i) { w.z[i] = take(zs[i] * B); w.a[i] = take(as[i] * B); }
+    for (int i = 0; i < 4; ++i) { w.z[i] = take(i == 0 ? 0 : zs[i] * B); w.a[i] = take(as[i] * B); }   // z1 is never materialised (kws_layer1.h)
     w.d1 = take((size_t)B * 128);
     w.loss_i = take(B);
     w.correct_i = take(B);
@@ -56,7 +57,7 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
         w.dlogits = take((size_t)B * m->C);
         w.dd1 = take((size_t)B * 128);
         w.da4 = take((size_t)B * d.flat);
-        for (int i = 0; i < 4; ++i) w.gz[i] = take(zs[i] * B);
+        for (int i = 0; i < 4; ++i) w.gz[i] = take(i == 0 ? 0 : zs[i] * B);
         for (int i = 0; i < 3; ++i) w.da[i] = take(as[i] * B);
     }
     w.bytes = off;
@@ -118,13 +119,30 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool pool[4] = {true, true, false, true};
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
 
-    for (int l = 0; l < 4; ++l) {
-        const float *in = l == 0 ? feat : w.a[l - 1];
+    // layer 1: conv1 is recomputed from the feature map wherever z1 is needed (kws_layer1.h)
+    {
+        const int cpb = std::max(1, (B + kMaxStatBlocks - 1) / kMaxStatBlocks), nb = (B + cpb - 1) / cpb;
+        const size_t smem1 = sizeof(float) * (size_t)(d.H0 + 2) * (d.W0 + 2);
+        const long M1 = (long)B * d.H0 * d.W0;
+        BnCoef k1 = coef_of(w.coef[0], 16);
+        const float *kern1 = params + m->o_k[0];
+        if (training) {
+            KWS_LAUNCH("l1_stats_kernel", l1_stats_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, B, d.H0, d.W0, cpb, w.partial);
+            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", 1), bn_finalize_train_kernel, dim3(16), dim3(256), 0, s, w.partial, nb, M1, 16,
+                       params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1);
+        } else {
+            KWS_LAUNCH(prof_name("bn_infer_coef_kernel", 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, 16, params + m->o_g[0],
+                       params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1);
+        }
+        KWS_LAUNCH("l1_act_pool_kernel", l1_act_pool_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
+                   d.H0, d.W0, cpb);
+    }
+    for (int l = 1; l < 4; ++l) {
+        const float *in = w.a[l - 1];
         const float *kern = params + m->o_k[l];
         const long M = (long)B * Hz[l] * Wz[l];
         const int C = kCh[l + 1];
-        if (l == 0) {
-            KWS_LAUNCH("conv1_fwd_kernel", conv1_fwd_kernel<16>, dim3(blocks_for(M, 256)), dim3(256), 0, s, in, kern, w.z[0], B, d.H0, d.W0);
+        if (false) {
         } else if (l == 1) {
             launch_gemm<16, 32, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[1], geom3x3(B, Hs[1], Ws[1], 1), s);
         } else if (l == 2) {
@@ -189,7 +207,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s);
         launch_gemm<128, 128, MODE_DGRAD, EPI_NONE>(w.dd1, params + m->o_dk, nullptr, w.da4, g, s);
     }
-    for (int l = 3; l >= 0; --l) {
+    for (int l = 3; l >= 1; --l) {
         const int C = kCh[l + 1];
         const long M = (long)B * Hz[l] * Wz[l];
         const float *da = l == 3 ? w.da4 : w.da[l];
@@ -229,12 +247,21 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const ConvGeom g = geom3x3(B, Hs[1], Ws[1], 1);
             launch_wgrad<16, 32, 9>(in, w.gz[1], dk, g, s);
             launch_gemm<32, 16, MODE_DGRAD, EPI_NONE>(w.gz[1], kern, nullptr, w.da[0], g, s);
-        } else {
-            const int cpw = std::max(1, B / 2048);                       // clips per wave: ~512+ blocks of 4 waves
-            const unsigned nb2 = blocks_for(B, 4 * cpw);
-            const size_t smem1 = sizeof(float) * (size_t)std::max(4 * (d.H0 + 2) * (d.W0 + 2), 4 * 256);
-            KWS_LAUNCH("conv1_wgrad_kernel", conv1_wgrad_kernel, dim3(nb2), dim3(256), smem1, s, in, w.gz[0], dk, B, d.H0, d.W0, cpw);
         }
+    }
+    // layer 1: da1 -> (dgamma1, dbeta1, dW1) with conv1 recomputed; no z1-sized tensor is read or written
+    {
+        const int cpb = std::max(1, (B + kMaxStatBlocks - 1) / kMaxStatBlocks), nb = (B + cpb - 1) / cpb;
+        const size_t smem1 = sizeof(float) * (size_t)(d.H0 + 2) * (d.W0 + 2);
+        const long M1 = (long)B * d.H0 * d.W0;
+        BnCoef k1 = coef_of(w.coef[0], 16);
+        const float *kern1 = params + m->o_k[0];
+        KWS_LAUNCH("l1_bwd_reduce_kernel", l1_bwd_reduce_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
+                   cpb, w.partial);
+        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(256), 0, s, w.partial, nb, M1, 16,
+                   params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], k1);
+        KWS_LAUNCH("l1_bwd_wgrad_kernel", l1_bwd_wgrad_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
+                   grads + m->o_k[0], B, d.H0, d.W0, cpb);
     }
     KWS_LAUNCH_CHECK("simple_cnn backward");
     return KWS_OK;

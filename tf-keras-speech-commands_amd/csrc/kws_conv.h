@@ -273,6 +273,127 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// WGRAD, LDS-free: every MFMA fragment comes straight from global memory.
+//   A^T fragment (row = input channel, k = pixel): lane (li, lq) reads x[pix(p0+lq) + tap][cb + 16 mt + li]
+//   B   fragment (k = pixel, col = out channel):   lane (li, lq) reads dz[p0+lq][16 nt + li]
+// i.e. four 64-byte segments per load; the GPB taps of a block re-touch the same lines (L1/L2 hits).  Each wave owns a
+// contiguous range of 4-pixel steps and ALL GPB*MT*NT output tiles of the block (A fragments are reused across NT,
+// B fragments across GPB*MT), so there is no staging, no barrier and one LDS reduction + one atomic set per block.
+// ---------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int GPB>
+__global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__restrict__ x, const float *__restrict__ dz,
+                                                                 float *__restrict__ dw, ConvGeom g, int steps_per_wave)
+{
+    constexpr int CB = CIN >= 64 ? 64 : CIN;
+    constexpr int CBLK = CIN / CB;
+    constexpr int MT = CB / 16, NT = COUT / 16;
+    static_assert(CIN % CB == 0 && CB % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
+    extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][64 lanes][4] per tile round
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    const int HoWo = g.Ho * g.Wo;
+    const int ngroups = g.KH * g.KW * CBLK, grp0 = blockIdx.y * GPB;
+    const long step0 = ((long)blockIdx.x * 4 + wave) * steps_per_wave;
+
+    // per-group constants (wave-uniform): tap coordinates and the tap's constant element offset from the pixel's base
+    int kh[GPB], kw[GPB], cb[GPB], toff[GPB];
+    bool gok[GPB];
+#pragma unroll
+    for (int gi = 0; gi < GPB; ++gi) {
+        const int grp = grp0 + gi, tap = grp / CBLK;
+        gok[gi] = grp < ngroups;
+        kh[gi] = tap / g.KW;
+        kw[gi] = tap % g.KW;
+        cb[gi] = (grp % CBLK) * CB;
+        toff[gi] = (kh[gi] * g.W + kw[gi]) * CIN + cb[gi];
+    }
+
+    f32x4 acc[GPB][MT][NT];
+#pragma unroll
+    for (int gi = 0; gi < GPB; ++gi)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[gi][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // this lane's pixel p = 4*step + lq, decoded once and advanced by 4 per step
+    long p = step0 * 4 + lq;
+    int b = (int)(p / HoWo), rem = (int)(p % HoWo), oh = rem / g.Wo, ow = rem % g.Wo;
+    // 32-bit element offsets (the host checks that both tensors have < 2^31 elements)
+    auto load_frags = [&](float (&af)[GPB][MT], float (&bf)[NT]) {
+        const bool pok = p < M;
+        const int dzo = pok ? (int)p * COUT + li : li;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = dz[dzo + 16 * nt];
+        const int y0 = oh * g.stride - g.pt, x0 = ow * g.stride - g.pl;
+        const int base = ((b * g.H + y0) * g.W + x0) * CIN + li;      // may point into the halo; used only when in range
+#pragma unroll
+        for (int gi = 0; gi < GPB; ++gi) {
+            const bool ok = pok && gok[gi] && (unsigned)(y0 + kh[gi]) < (unsigned)g.H && (unsigned)(x0 + kw[gi]) < (unsigned)g.W;
+            const int o = ok ? base + toff[gi] : li;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float v = x[o + 16 * mt];              // unconditional load from a clamped offset, masked below
+                af[gi][mt] = ok ? v : 0.f;
+            }
+        }
+        if (!pok) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = 0.f;
+        }
+        p += 4;
+        ow += 4;
+        while (ow >= g.Wo) { ow -= g.Wo; ++oh; }
+        while (oh >= g.Ho) { oh -= g.Ho; ++b; }
+    };
+    const long left = (M + 3) / 4 - step0;
+    const int nst = left <= 0 ? 0 : (left < steps_per_wave ? (int)left : steps_per_wave);
+    float afn[GPB][MT], bfn[NT];
+    if (nst > 0) load_frags(afn, bfn);
+    for (int st = 0; st < nst; ++st) {
+        float af[GPB][MT], bf[NT];
+#pragma unroll
+        for (int gi = 0; gi < GPB; ++gi)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[gi][mt] = afn[gi][mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = bfn[nt];
+        if (st + 1 < nst) load_frags(afn, bfn);          // next step's fragments fly while this step's MFMAs issue
+#pragma unroll
+        for (int gi = 0; gi < GPB; ++gi)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[gi][mt][nt] = mfma16(af[gi][mt], bf[nt], acc[gi][mt][nt]);
+    }
+
+    // reduce the 4 waves' partial tiles through LDS, one tile at a time, then add to global memory
+#pragma unroll
+    for (int gi = 0; gi < GPB; ++gi)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                __syncthreads();
+                *reinterpret_cast<f32x4 *>(&red[(wave * 64 + lane) * 4]) = acc[gi][mt][nt];
+                __syncthreads();
+                if (wave == 0 && gok[gi]) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&red[(0 * 64 + lane) * 4]);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&red[(1 * 64 + lane) * 4]);
+                    const f32x4 a2 = *reinterpret_cast<const f32x4 *>(&red[(2 * 64 + lane) * 4]);
+                    const f32x4 a3 = *reinterpret_cast<const f32x4 *>(&red[(3 * 64 + lane) * 4]);
+                    const int tap = (grp0 + gi) / CBLK;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = cb[gi] + 16 * mt + 4 * lq + r, co = 16 * nt + li;
+                        atomicAdd(dw + ((long)(tap * CIN + ci)) * COUT + co, (a0[r] + a1[r]) + (a2[r] + a3[r]));
+                    }
+                }
+            }
+}
+
 template <int CIN, int COUT, int GPB>
 constexpr size_t conv_wgrad_smem()
 {

@@ -91,13 +91,14 @@ void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g,
     constexpr int CB = CIN >= 64 ? 64 : CIN;
     const long M = (long)g.B * g.Ho * g.Wo;
     const int ngroups = g.KH * g.KW * (CIN / CB), gy = (ngroups + GPB - 1) / GPB;
-    const long steps = (M + 63) / 64;
-    long gx = std::max<long>(1, std::min<long>(steps, 1024 / gy));
-    const int spb = (int)((steps + gx - 1) / gx);
-    gx = (steps + spb - 1) / spb;
-    const size_t smem = conv_wgrad_smem<CIN, COUT, GPB>();
+    const long steps = (M + 3) / 4;                                   // 4-pixel MFMA k-steps
+    // >= 8 steps per wave so the end-of-block tile reduction amortises; <= ~1024 blocks in total
+    const long waves = std::max<long>(4, std::min<long>((steps + 7) / 8, 4L * std::max(1, 1024 / gy)));
+    const int spw = (int)((steps + waves - 1) / waves);
+    const long gx = (steps + 4L * spw - 1) / (4L * spw);
     static const std::string name = "conv_wgrad<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
-    KWS_LAUNCH(name.c_str(), (conv_wgrad_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), smem, s, x, dz, dw, g, spb);
+    KWS_LAUNCH(name.c_str(), (conv_wgrad_direct_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 4 * 64 * 4 * sizeof(float),
+               s, x, dz, dw, g, spw);
 }
 
 ConvGeom geom3x3(int B, int H, int W, int stride)

@@ -394,6 +394,115 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
             }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// DGRAD, LDS-free.  dx[m][n] = sum_{tap, c} dz[pixT(m, tap)][c] * W[tap][n][c]   (HWIO: I = n = CO, O = c = CR)
+// Both operands are contiguous along c, so with the K order permuted to k = 16 jj + 4 lq + j every lane fetches ONE
+// float4 per fragment and feeds four MFMA k-steps from it (element j of the A and of the B vector share the same k).
+// A wave owns MW x 16 rows (input pixels) and all CO/16 column tiles; W fragments come from L1/L2 (<= 288 KB, shared
+// by every wave), dz rows are 64-byte segments.  Strided convolutions are launched once per parity class
+// (cy, cx): rows of a class share the set of contributing taps, so no zero tap is ever multiplied.
+// ---------------------------------------------------------------------------------------------------------------
+struct DgradClass { int cy, cx, ny, nx; };   // rows of the class: ih = stride*a + cy (a < ny), iw = stride*b + cx (b < nx)
+
+template <int CR, int CO, int MW, int STRIDE>
+__global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__restrict__ dz, const float *__restrict__ wgt,
+                                                                 float *__restrict__ dx, ConvGeom g, DgradClass cls)
+{
+    constexpr int NT = CO / 16, JJ = CR / 16;
+    static_assert(CR % 16 == 0 && CO % 16 == 0, "channel counts must be multiples of 16");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const long Mc = (long)g.B * cls.ny * cls.nx;                      // rows of this class
+    const long m0 = ((long)blockIdx.x * 4 + wave) * (16 * MW);
+    if (m0 >= Mc) return;
+
+    // A-fragment rows of this lane (row li of each of the MW tiles)
+    int rb[MW], ry[MW], rx[MW];
+    bool rok[MW];
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt) {
+        const long m = m0 + 16 * mt + li;
+        rok[mt] = m < Mc;
+        const long mm = rok[mt] ? m : 0;
+        const int rem = (int)(mm % ((long)cls.ny * cls.nx));
+        rb[mt] = (int)(mm / ((long)cls.ny * cls.nx));
+        ry[mt] = (rem / cls.nx) * STRIDE + cls.cy + g.pt;         // + pad: ty = ry - kh below
+        rx[mt] = (rem % cls.nx) * STRIDE + cls.cx + g.pl;
+    }
+    // taps that reach this class: kh == (cy + pt) (mod stride)
+    const int kh0 = (cls.cy + g.pt) % STRIDE, kw0 = (cls.cx + g.pl) % STRIDE;
+
+    f32x4 acc[MW][NT];
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nkh = (g.KH - kh0 + STRIDE - 1) / STRIDE, nkw = (g.KW - kw0 + STRIDE - 1) / STRIDE;
+    const int nit = nkh * nkw * JJ;
+    // iteration -> (tap row, tap col, channel block) kept incrementally: no division in the loop
+    int n_th = 0, n_tw = 0, n_jj = 0;
+    auto load_frags = [&](float4 (&af)[MW], float4 (&bf)[NT]) {
+        const int kh = kh0 + n_th * STRIDE, kw = kw0 + n_tw * STRIDE, jj = n_jj;
+        const int tap = kh * g.KW + kw;
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) {
+            const int ty = ry[mt] - kh, tx = rx[mt] - kw;                    // multiples of STRIDE by construction
+            const int oh = ty / STRIDE, ow = tx / STRIDE;                    // compile-time divisor
+            const bool ok = rok[mt] && ty >= 0 && tx >= 0 && oh < g.Ho && ow < g.Wo;
+            const int o = ok ? ((rb[mt] * g.Ho + oh) * g.Wo + ow) * CR + 16 * jj + 4 * lq : 4 * lq;
+            const float4 v = *reinterpret_cast<const float4 *>(dz + o);
+            af[mt] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            bf[nt] = *reinterpret_cast<const float4 *>(wgt + (tap * CO + 16 * nt + li) * CR + 16 * jj + 4 * lq);
+        if (++n_jj == JJ) { n_jj = 0; if (++n_tw == nkw) { n_tw = 0; ++n_th; } }
+    };
+
+    float4 afn[MW], bfn[NT];
+    load_frags(afn, bfn);
+    for (int it = 0; it < nit; ++it) {
+        float4 af[MW], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) af[mt] = afn[mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = bfn[nt];
+        if (it + 1 < nit) load_frags(afn, bfn);
+        // k-step outermost: consecutive MFMAs hit different accumulators (dependent-issue latency is 40 cycles, not 32)
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(af[mt].x, bf[nt].x, acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(af[mt].y, bf[nt].y, acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(af[mt].z, bf[nt].z, acc[mt][nt]);
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(af[mt].w, bf[nt].w, acc[mt][nt]);
+    }
+
+    // D layout: row = 4*lq + r, col = li
+#pragma unroll
+    for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = m0 + 16 * mt + 4 * lq + r;
+            if (m < Mc) {
+                const int rem = (int)(m % ((long)cls.ny * cls.nx)), b = (int)(m / ((long)cls.ny * cls.nx));
+                const int ih = (rem / cls.nx) * STRIDE + cls.cy, iw = (rem % cls.nx) * STRIDE + cls.cx;
+                float *o = dx + (((long)b * g.H + ih) * g.W + iw) * CO + li;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) o[16 * nt] = acc[mt][nt][r];
+            }
+        }
+}
+
 template <int CIN, int COUT, int GPB>
 constexpr size_t conv_wgrad_smem()
 {

@@ -372,20 +372,22 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restric
 }
 
 // head backward: dx[b][k] = sum_c dlogits[b][c] W2[k][c], gated by the ReLU6 of x (x = relu6 output: 0 < x < 6);
-// dW2[k][c] += sum_b x[b][k] dlogits[b][c]; db2[c] += sum_b dlogits[b][c].  block = 64 samples.
+// dW2[k][c] += sum_b x[b][k] dlogits[b][c]; db2[c] += sum_b dlogits[b][c].  block = kHeadBwdRows samples.
+constexpr int kHeadBwdRows = 16;
+
 template <bool RELU6_GATE>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__ x, const float *__restrict__ w2,
                                                         const float *__restrict__ dlogits, float *__restrict__ dx,
                                                         float *__restrict__ dw2, float *__restrict__ db2, int B, int K, int C)
 {
     extern __shared__ float hs[];
-    float *xs = hs;              // [64][K]
-    float *ds = hs + 64 * K;     // [64][C]
-    const int b0 = blockIdx.x * 64;
-    for (int i = threadIdx.x; i < 64 * K; i += 256) xs[i] = (b0 + i / K < B) ? x[(long)(b0 + i / K) * K + (i % K)] : 0.f;
-    for (int i = threadIdx.x; i < 64 * C; i += 256) ds[i] = (b0 + i / C < B) ? dlogits[(long)(b0 + i / C) * C + (i % C)] : 0.f;
+    float *xs = hs;              // [R][K]
+    float *ds = hs + kHeadBwdRows * K;     // [R][C]
+    const int b0 = blockIdx.x * kHeadBwdRows;
+    for (int i = threadIdx.x; i < kHeadBwdRows * K; i += 256) xs[i] = (b0 + i / K < B) ? x[(long)(b0 + i / K) * K + (i % K)] : 0.f;
+    for (int i = threadIdx.x; i < kHeadBwdRows * C; i += 256) ds[i] = (b0 + i / C < B) ? dlogits[(long)(b0 + i / C) * C + (i % C)] : 0.f;
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * K; i += 256) {
+    for (int i = threadIdx.x; i < kHeadBwdRows * K; i += 256) {
         const int s = i / K, k = i % K;
         if (b0 + s >= B) continue;
         float acc = 0.f;
@@ -396,12 +398,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
     for (int i = threadIdx.x; i < K * C; i += 256) {
         const int k = i / C, c = i % C;
         float acc = 0.f;
-        for (int s = 0; s < 64; ++s) acc = fmaf(xs[s * K + k], ds[s * C + c], acc);
+        for (int s = 0; s < kHeadBwdRows; ++s) acc = fmaf(xs[s * K + k], ds[s * C + c], acc);
         atomicAdd(dw2 + i, acc);
     }
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = 0.f;
-        for (int s = 0; s < 64; ++s) acc += ds[s * C + c];
+        for (int s = 0; s < kHeadBwdRows; ++s) acc += ds[s * C + c];
         atomicAdd(db2 + c, acc);
     }
 }

@@ -101,6 +101,20 @@ void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g,
                s, x, dz, dw, g, spw);
 }
 
+// dx <- dgrad(dz): one launch per stride-parity class of the input pixels
+template <int CR, int CO, int MW, int STRIDE>
+void launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g, hipStream_t s)
+{
+    static const std::string name = "conv_dgrad<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
+    for (int cy = 0; cy < g.stride; ++cy)
+        for (int cx = 0; cx < g.stride; ++cx) {
+            DgradClass c{cy, cx, (g.H - cy + g.stride - 1) / g.stride, (g.W - cx + g.stride - 1) / g.stride};
+            if (c.ny <= 0 || c.nx <= 0) continue;
+            const long Mc = (long)g.B * c.ny * c.nx;
+            KWS_LAUNCH(name.c_str(), (conv_dgrad_direct_kernel<CR, CO, MW, STRIDE>), dim3(blocks_for(Mc, 64 * MW)), dim3(256), 0, s, dz, w, dx, g, c);
+        }
+}
+
 ConvGeom geom3x3(int B, int H, int W, int stride)
 {
     ConvGeom g;
@@ -206,7 +220,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
         KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
         launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s);
-        launch_gemm<128, 128, MODE_DGRAD, EPI_NONE>(w.dd1, params + m->o_dk, nullptr, w.da4, g, s);
+        launch_dgrad<128, 128, 2, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
     }
     for (int l = 3; l >= 1; --l) {
         const int C = kCh[l + 1];
@@ -239,15 +253,15 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s);
             // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final from here on
             if (bucket_event) KWS_HIP_CHECK(hipEventRecord(bucket_event, s));
-            launch_gemm<128, 64, MODE_DGRAD, EPI_NONE>(w.gz[3], kern, nullptr, w.da[2], g, s);
+            launch_dgrad<128, 64, 4, 1>(w.gz[3], kern, w.da[2], g, s);
         } else if (l == 2) {
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
             launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s);
-            launch_gemm<64, 32, MODE_DGRAD, EPI_NONE>(w.gz[2], kern, nullptr, w.da[1], g, s);
+            launch_dgrad<64, 32, 4, 2>(w.gz[2], kern, w.da[1], g, s);
         } else if (l == 1) {
             const ConvGeom g = geom3x3(B, Hs[1], Ws[1], 1);
             launch_wgrad<16, 32, 9>(in, w.gz[1], dk, g, s);
-            launch_gemm<32, 16, MODE_DGRAD, EPI_NONE>(w.gz[1], kern, nullptr, w.da[0], g, s);
+            launch_dgrad<32, 16, 4, 1>(w.gz[1], kern, w.da[0], g, s);
         }
     }
     // layer 1: da1 -> (dgamma1, dbeta1, dW1) with conv1 recomputed; no z1-sized tensor is read or written
@@ -298,12 +312,12 @@ int run_head_bwd(const kws_model *m, int B, const float *params, const float *x,
                  float *grads, bool relu6_gate, hipStream_t s)
 {
     const int K = m->head_K;
-    const size_t smem = sizeof(float) * (size_t)(64 * K + 64 * m->C);
+    const size_t smem = sizeof(float) * (size_t)(kHeadBwdRows * K + kHeadBwdRows * m->C);
     if (relu6_gate)
-        KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<true>, dim3(blocks_for(B, 64)), dim3(256), smem, s, x, params + m->o_hk, dlogits,
+        KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<true>, dim3(blocks_for(B, kHeadBwdRows)), dim3(256), smem, s, x, params + m->o_hk, dlogits,
                    dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
     else
-        KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<false>, dim3(blocks_for(B, 64)), dim3(256), smem, s, x, params + m->o_hk, dlogits,
+        KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<false>, dim3(blocks_for(B, kHeadBwdRows)), dim3(256), smem, s, x, params + m->o_hk, dlogits,
                    dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
     KWS_LAUNCH_CHECK("head backward");
     return KWS_OK;

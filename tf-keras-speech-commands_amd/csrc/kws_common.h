@@ -39,6 +39,10 @@ inline int fail(int code, const char *fmt, ...)
             return ::kws::fail(KWS_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e__)); \
     } while (0)
 
+// 4 KB of zeros on the current device (allocated once per device): padding rows of the convolutions are READ from here
+// instead of being masked after the load, so a fragment load has no consumer until its MFMA (the prefetch can overlap).
+const float *zero_page();
+
 // Opt-in per-launch timing (kws_prof_enable / kws_prof_report): HIP events recorded on the launch stream around each
 // kernel.  Disabled (the default) it costs one relaxed load per launch site.
 bool prof_on();

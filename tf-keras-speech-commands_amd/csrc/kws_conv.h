@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int GPB>
 __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__restrict__ x, const float *__restrict__ dz,
-                                                                 float *__restrict__ dw, ConvGeom g, int steps_per_wave)
+                                                                 float *__restrict__ dw, const float *__restrict__ zeros,
+                                                                 ConvGeom g, int steps_per_wave)
 {
     constexpr int CB = CIN >= 64 ? 64 : CIN;
     constexpr int CBLK = CIN / CB;
@@ -323,25 +324,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
     int b = (int)(p / HoWo), rem = (int)(p % HoWo), oh = rem / g.Wo, ow = rem % g.Wo;
     // 32-bit element offsets (the host checks that both tensors have < 2^31 elements)
     auto load_frags = [&](float (&af)[GPB][MT], float (&bf)[NT]) {
+        // out-of-range pixels / padding taps read the zero page: no op touches a loaded value before its MFMA
         const bool pok = p < M;
-        const int dzo = pok ? (int)p * COUT + li : li;
+        const float *dzp = pok ? dz + ((int)p * COUT + li) : zeros + li;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = dz[dzo + 16 * nt];
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = dzp[16 * nt];
         const int y0 = oh * g.stride - g.pt, x0 = ow * g.stride - g.pl;
         const int base = ((b * g.H + y0) * g.W + x0) * CIN + li;      // may point into the halo; used only when in range
 #pragma unroll
         for (int gi = 0; gi < GPB; ++gi) {
             const bool ok = pok && gok[gi] && (unsigned)(y0 + kh[gi]) < (unsigned)g.H && (unsigned)(x0 + kw[gi]) < (unsigned)g.W;
-            const int o = ok ? base + toff[gi] : li;
+            const float *xp = ok ? x + (base + toff[gi]) : zeros + li;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const float v = x[o + 16 * mt];              // unconditional load from a clamped offset, masked below
-                af[gi][mt] = ok ? v : 0.f;
-            }
-        }
-        if (!pok) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[nt] = 0.f;
+            for (int mt = 0; mt < MT; ++mt) af[gi][mt] = xp[16 * mt];
         }
         p += 4;
         ow += 4;
@@ -406,7 +401,8 @@ struct DgradClass { int cy, cx, ny, nx; };   // rows of the class: ih = stride*a
 
 template <int CR, int CO, int MW, int STRIDE>
 __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__restrict__ dz, const float *__restrict__ wgt,
-                                                                 float *__restrict__ dx, ConvGeom g, DgradClass cls)
+                                                                 float *__restrict__ dx, const float *__restrict__ zeros,
+                                                                 ConvGeom g, DgradClass cls)
 {
     constexpr int NT = CO / 16, JJ = CR / 16;
     static_assert(CR % 16 == 0 && CO % 16 == 0, "channel counts must be multiples of 16");
@@ -415,21 +411,40 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__r
     const long m0 = ((long)blockIdx.x * 4 + wave) * (16 * MW);
     if (m0 >= Mc) return;
 
-    // A-fragment rows of this lane (row li of each of the MW tiles)
-    int rb[MW], ry[MW], rx[MW];
-    bool rok[MW];
-#pragma unroll
-    for (int mt = 0; mt < MW; ++mt) {
-        const long m = m0 + 16 * mt + li;
-        rok[mt] = m < Mc;
-        const long mm = rok[mt] ? m : 0;
-        const int rem = (int)(mm % ((long)cls.ny * cls.nx));
-        rb[mt] = (int)(mm / ((long)cls.ny * cls.nx));
-        ry[mt] = (rem / cls.nx) * STRIDE + cls.cy + g.pt;         // + pad: ty = ry - kh below
-        rx[mt] = (rem % cls.nx) * STRIDE + cls.cx + g.pl;
-    }
-    // taps that reach this class: kh == (cy + pt) (mod stride)
+    // taps that reach this class: kh = kh0 + th*STRIDE with kh0 == (cy + pt) (mod STRIDE); likewise kw
     const int kh0 = (cls.cy + g.pt) % STRIDE, kw0 = (cls.cx + g.pl) % STRIDE;
+    const int nkh = (g.KH - kh0 + STRIDE - 1) / STRIDE, nkw = (g.KW - kw0 + STRIDE - 1) / STRIDE;
+    const int nit = nkh * nkw * JJ;
+
+    // A-fragment rows of this lane (row li of each of the MW tiles): decoded ONCE into
+    //   rbase = element offset of dz[b][oh0][ow0][4*lq] with (oh0, ow0) the source pixel of tap (kh0, kw0); the source of
+    //           tap (th, tw) is (oh0 - th, ow0 - tw), i.e. rbase - (th*Wo + tw)*CR  (one scalar offset per tap)
+    //   rmask = bit th     : 0 <= oh0 - th < Ho      bit 8 + tw : 0 <= ow0 - tw < Wo      (0 when the row is out of range)
+    // so the K loop spends one add and one mask test per row instead of re-deriving the address with multiplies.
+    int rbase[MW], rmask[MW];
+    {
+        const long m = m0 + li;
+        const long mm = m < Mc ? m : 0;
+        const int per = cls.ny * cls.nx, rem = (int)(mm % per);
+        int b = (int)(mm / per), a = rem / cls.nx, c = rem % cls.nx;
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt) {
+            const int oh0 = (a * STRIDE + cls.cy + g.pt - kh0) / STRIDE, ow0 = (c * STRIDE + cls.cx + g.pl - kw0) / STRIDE;
+            rbase[mt] = ((b * g.Ho + oh0) * g.Wo + ow0) * CR + 4 * lq;
+            int msk = 0;
+            if (m + 16 * mt < Mc) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {                                 // up to 8 taps per axis (host-checked)
+                    if (t < nkh && oh0 - t >= 0 && oh0 - t < g.Ho) msk |= 1 << t;
+                    if (t < nkw && ow0 - t >= 0 && ow0 - t < g.Wo) msk |= 256 << t;
+                }
+            }
+            rmask[mt] = msk;
+            c += 16;
+            while (c >= cls.nx) { c -= cls.nx; ++a; }
+            while (a >= cls.ny) { a -= cls.ny; ++b; }
+        }
+    }
 
     f32x4 acc[MW][NT];
 #pragma unroll
@@ -437,38 +452,28 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__r
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nkh = (g.KH - kh0 + STRIDE - 1) / STRIDE, nkw = (g.KW - kw0 + STRIDE - 1) / STRIDE;
-    const int nit = nkh * nkw * JJ;
-    // iteration -> (tap row, tap col, channel block) kept incrementally: no division in the loop
+    // iteration -> (tap row, tap col, channel block) kept incrementally in scalars: no division in the loop
     int n_th = 0, n_tw = 0, n_jj = 0;
+    const int wrow = (16 * 0 + li) * CR + 4 * lq;                            // this lane's offset inside a W[tap] slab
     auto load_frags = [&](float4 (&af)[MW], float4 (&bf)[NT]) {
-        const int kh = kh0 + n_th * STRIDE, kw = kw0 + n_tw * STRIDE, jj = n_jj;
-        const int tap = kh * g.KW + kw;
+        const int tapoff = (n_th * g.Wo + n_tw) * CR - 16 * n_jj;            // wave-uniform
+        const int tapbit = (1 << n_th) | (256 << n_tw);
+        const bool live = n_th < nkh;                                         // false for the (harmless) loads past the end
+        const int tap = live ? (kh0 + n_th * STRIDE) * g.KW + kw0 + n_tw * STRIDE : 0;
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt) {
-            const int ty = ry[mt] - kh, tx = rx[mt] - kw;                    // multiples of STRIDE by construction
-            const int oh = ty / STRIDE, ow = tx / STRIDE;                    // compile-time divisor
-            const bool ok = rok[mt] && ty >= 0 && tx >= 0 && oh < g.Ho && ow < g.Wo;
-            const int o = ok ? ((rb[mt] * g.Ho + oh) * g.Wo + ow) * CR + 16 * jj + 4 * lq : 4 * lq;
-            const float4 v = *reinterpret_cast<const float4 *>(dz + o);
-            af[mt] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            // padding rows read the zero page: no op touches the loaded value before its MFMA, so the wait sits there
+            const bool ok = live && (rmask[mt] & tapbit) == tapbit;
+            af[mt] = *reinterpret_cast<const float4 *>(ok ? dz + (rbase[mt] - tapoff) : zeros + 4 * lq);
         }
+        const float *wp = wgt + (tap * CO) * CR + 16 * n_jj + wrow;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            bf[nt] = *reinterpret_cast<const float4 *>(wgt + (tap * CO + 16 * nt + li) * CR + 16 * jj + 4 * lq);
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const float4 *>(wp + 16 * nt * CR);
         if (++n_jj == JJ) { n_jj = 0; if (++n_tw == nkw) { n_tw = 0; ++n_th; } }
     };
 
-    float4 afn[MW], bfn[NT];
-    load_frags(afn, bfn);
-    for (int it = 0; it < nit; ++it) {
-        float4 af[MW], bf[NT];
-#pragma unroll
-        for (int mt = 0; mt < MW; ++mt) af[mt] = afn[mt];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = bfn[nt];
-        if (it + 1 < nit) load_frags(afn, bfn);
-        // k-step outermost: consecutive MFMAs hit different accumulators (dependent-issue latency is 40 cycles, not 32)
+    auto mma = [&](const float4 (&af)[MW], const float4 (&bf)[NT]) {
+        // k-step outermost: consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
@@ -485,18 +490,47 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__r
         for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mfma16(af[mt].w, bf[nt].w, acc[mt][nt]);
+    };
+    // Explicit two-set ping-pong (no loop-carried register copies): set 1 loads fly while set 0 feeds the MFMAs.
+    // The waves of a SIMD run this loop in lockstep, so a body of [address math + loads][MFMA batch] leaves the matrix
+    // pipe idle while everyone computes addresses and the vector ALU idle while everyone multiplies (measured: 2.5k +
+    // 2.2k + wait cycles per iteration).  sched_group_barrier interleaves the two streams instruction by instruction.
+    constexpr int NM = 4 * MW * NT;                        // MFMAs per fragment set
+    constexpr int VPM = (24 * MW + 6 * NT + NM - 1) / NM + 1;   // VALU ops to slot behind each MFMA
+    float4 a0[MW], b0[NT], a1[MW], b1[NT];
+    load_frags(a0, b0);
+    for (int it = 0; it < nit; it += 2) {
+        load_frags(a1, b1);                                // (past the end: masked rows, clamped tap -> harmless)
+        mma(a0, b0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);    // VALU
+            if (i < MW + NT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        }
+        load_frags(a0, b0);
+        if (it + 1 < nit) mma(a1, b1);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 1);
+            if (i < MW + NT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);
+        }
     }
 
-    // D layout: row = 4*lq + r, col = li
+    // D layout: row = 4*lq + r, col = li.  With stride 1 the class order is the pixel order: offset = m * CO.
 #pragma unroll
     for (int mt = 0; mt < MW; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long m = m0 + 16 * mt + 4 * lq + r;
             if (m < Mc) {
-                const int rem = (int)(m % ((long)cls.ny * cls.nx)), b = (int)(m / ((long)cls.ny * cls.nx));
-                const int ih = (rem / cls.nx) * STRIDE + cls.cy, iw = (rem % cls.nx) * STRIDE + cls.cx;
-                float *o = dx + (((long)b * g.H + ih) * g.W + iw) * CO + li;
+                long pix = m;
+                if (STRIDE != 1) {
+                    const int per = cls.ny * cls.nx, rem = (int)(m % per), b = (int)(m / per);
+                    pix = ((long)b * g.H + (rem / cls.nx) * STRIDE + cls.cy) * g.W + (rem % cls.nx) * STRIDE + cls.cx;
+                }
+                float *o = dx + pix * CO + li;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) o[16 * nt] = acc[mt][nt][r];
             }

@@ -29,6 +29,21 @@ hipEvent_t take_event()
 }
 }  // namespace
 
+const float *zero_page()
+{
+    static std::mutex mu;
+    static void *pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pages[dev]) {
+        void *p = nullptr;
+        if (hipMalloc(&p, 4096) != hipSuccess || hipMemset(p, 0, 4096) != hipSuccess) return nullptr;
+        pages[dev] = p;
+    }
+    return static_cast<const float *>(pages[dev]);
+}
+
 bool prof_on() { return g_prof_on.load(std::memory_order_relaxed); }
 
 const char *prof_name(const char *base, int layer)

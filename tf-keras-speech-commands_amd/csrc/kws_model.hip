@@ -98,7 +98,7 @@ void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g,
     const long gx = (steps + 4L * spw - 1) / (4L * spw);
     static const std::string name = "conv_wgrad<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
     KWS_LAUNCH(name.c_str(), (conv_wgrad_direct_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 4 * 64 * 4 * sizeof(float),
-               s, x, dz, dw, g, spw);
+               s, x, dz, dw, zero_page(), g, spw);
 }
 
 // dx <- dgrad(dz): one launch per stride-parity class of the input pixels
@@ -106,12 +106,13 @@ template <int CR, int CO, int MW, int STRIDE>
 void launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g, hipStream_t s)
 {
     static const std::string name = "conv_dgrad<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
+    if (g.KH > 8 * g.stride || g.KW > 8 * g.stride) { fail(KWS_ERR_UNSUPPORTED, "kernel %dx%d too large for the dgrad tap masks", g.KH, g.KW); return; }
     for (int cy = 0; cy < g.stride; ++cy)
         for (int cx = 0; cx < g.stride; ++cx) {
             DgradClass c{cy, cx, (g.H - cy + g.stride - 1) / g.stride, (g.W - cx + g.stride - 1) / g.stride};
             if (c.ny <= 0 || c.nx <= 0) continue;
             const long Mc = (long)g.B * c.ny * c.nx;
-            KWS_LAUNCH(name.c_str(), (conv_dgrad_direct_kernel<CR, CO, MW, STRIDE>), dim3(blocks_for(Mc, 64 * MW)), dim3(256), 0, s, dz, w, dx, g, c);
+            KWS_LAUNCH(name.c_str(), (conv_dgrad_direct_kernel<CR, CO, MW, STRIDE>), dim3(blocks_for(Mc, 64 * MW)), dim3(256), 0, s, dz, w, dx, zero_page(), g, c);
         }
 }
 

@@ -52,7 +52,10 @@ def test_fit_learns_and_matches_predict_oracle(torch, tmp_path):
     C = 4
     x, y = separable(1000, C, 1)
     xv, yv = separable(300, C, 2)
+    from kws_amd.init import init_weights
+    torch.manual_seed(0)                                   # fit() draws its shuffles from torch's device generator
     m = get_model("simple_cnn", C)
+    m.set_weights(init_weights(m.spec, seed=0))
     m.compile(get_optimizer("adam", 2e-3, decay_type="cosine", decay_steps=40), SparseCategoricalCrossEntropy(), ["accuracy"])
     log = os.path.join(tmp_path, "log.jsonl")
     ck = cb.ModelCheckpoint(os.path.join(tmp_path, "ep{epoch:03d}-val_accuracy{val_accuracy:.3f}.npz"), monitor="val_accuracy",
@@ -94,7 +97,10 @@ def test_fit_from_raw_audio_and_weighted_loss(torch):
     t = np.arange(16000) / 16000.0
     tones = np.stack([np.sin(2 * np.pi * f * t) for f in (300.0, 1200.0, 3000.0)])
     wav = (0.3 * tones[y] + 0.05 * rng.standard_normal((n, 16000))).astype(np.float32)
+    from kws_amd.init import init_weights
+    torch.manual_seed(1)
     m = get_model("simple_cnn", C)
+    m.set_weights(init_weights(m.spec, seed=1))
     w = np.array([0.2, 0.4, 0.4])
     m.compile(get_optimizer("adam", 2e-3, decay_type=None), WeightedSparseCategoricalCrossEntropy(w), ["accuracy"])
     h = m.fit(wav, y, batch_size=128, epochs=8, verbose=0)

@@ -216,8 +216,78 @@ def test_gru_host_api_fit(torch):
     protos = rng.standard_normal((C, 30, 20)) * 1.5
     y = rng.integers(0, C, n)
     x = (protos[y] + 0.5 * rng.standard_normal((n, 30, 20))).astype(np.float32)[..., None]   # dataset arrays are (N,30,20,1)
+    from kws_amd.init import init_weights
+    torch.manual_seed(2)
     m = get_model("simple_gru", C)
+    m.set_weights(init_weights(m.spec, seed=2))
     assert m.input_shape == (30, 20) and m.count_params() == 20 * 144 + 48 * 144 + 288 + 48 * C + C
     m.compile(get_optimizer("adam", 5e-3, decay_type=None), SparseCategoricalCrossEntropy(), ["accuracy"])
     h = m.fit(x, y, batch_size=128, epochs=12, verbose=0)
     assert h.history["accuracy"][-1] > 0.9 and h.history["loss"][-1] < 0.5 * h.history["loss"][0]
+
+
+# ---- simple_cnn_lite (classifier/models/cnn.py:77-141) ----------------------------------------------------------
+def test_lite_tensor_table(torch):
+    from kws_amd.model import ModelSpec
+    from oracle import model_oracle as mo
+    spec = ModelSpec("simple_cnn_lite", 36, 30, 20)
+    om = mo.Model("simple_cnn_lite", 36)
+    assert spec.trainable_count() == om.trainable_count() == 50045
+    assert [t["shape"] for t in spec.tensors] == [w.shape for w in om.get_weights()]
+    assert [t["name"] for t in spec.tensors[:3]] == ["separable_conv2d/depthwise_kernel", "separable_conv2d/pointwise_kernel",
+                                                     "separable_conv2d/bias"]
+
+
+@pytest.mark.parametrize("B", [1, 33, 64])
+def test_lite_inference_forward(torch, B):
+    om, dm = build("simple_cnn_lite", 36)
+    x = features(B, 23)
+    probs, am = dm.forward(torch.from_numpy(x).cuda())
+    want = om.predict(x.astype(np.float64))
+    np.testing.assert_allclose(probs.cpu().numpy(), want, atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
+
+
+@pytest.mark.parametrize("weighted,seed", [(False, 0), (True, 0x77AA55)])
+def test_lite_train_forward_backward(torch, weighted, seed):
+    from oracle import model_oracle as mo
+    C, B = 10, 40
+    om, dm = build("simple_cnn_lite", C)
+    x = features(B, 25)
+    y = np.random.default_rng(26).integers(0, C, B)
+    cw = np.array([0.3] + [0.7 / (C - 1)] * (C - 1)) if weighted else None
+    loss, acc, p = mo.train_forward_backward(om, x.astype(np.float64), y, cw, dropout_seed=seed or None)
+    probs = dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(),
+                             torch.from_numpy(cw.astype(np.float32)).cuda() if weighted else None, dropout_seed=seed,
+                             want_probs=True)
+    stats = dm.stats.cpu().numpy()
+    np.testing.assert_allclose(probs.cpu().numpy(), p, atol=1e-4, rtol=0)
+    assert abs(stats[0] / B - loss) < 1e-4 and stats[1] == round(acc * B)
+    for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
+        # a bias in front of BatchNormalization has an exactly-zero gradient (oracle ~1e-16): absolute floor 1e-6
+        err = float(np.abs(g - want).max())
+        assert err < 3e-4 * float(np.abs(want).max()) + 1e-6, "gradient of layer %d %s: abs err %g" % (li, n, err)
+    got_w = dm.get_weights()
+    for i, (li, n, t) in enumerate(om.weight_list()):
+        if not t:
+            np.testing.assert_allclose(got_w[i], om.get_weights()[i], rtol=2e-5, atol=1e-6, err_msg=n)
+
+
+def test_lite_multi_step_training_tracks_oracle(torch):
+    from oracle import model_oracle as mo
+    C, B = 5, 64
+    om, dm = build("simple_cnn_lite", C, seed=6, perturb=False)
+    rng = np.random.default_rng(31)
+    protos = rng.standard_normal((C, 30, 20)) * 2
+    opt = mo.Adam(1e-3)   # the reference's default learning rate (train.py:128)
+    for it in range(8):
+        y = rng.integers(0, C, B)
+        x = (protos[y] + 0.5 * rng.standard_normal((B, 30, 20))).astype(np.float32)
+        lo, _ = mo.train_step(om, opt, x.astype(np.float64), y, dropout_seed=900 + it)
+        dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(), dropout_seed=900 + it)
+        dm.adam_step(1e-3)
+        # Stage 1 of the lite model (1-channel depthwise -> pointwise -> BatchNorm) is scale invariant, so some depthwise
+        # gradient components are ~0; Adam's first steps move those weights by +-lr on the SIGN of fp32 noise (measured:
+        # one weight differs by exactly 2*lr after step 0 while every gradient matches to 3e-4).  simple_cnn, which has no
+        # such direction, tracks the oracle to 1e-7 with the same code.  Hence 5e-3 here instead of 1e-3.
+        assert abs(float(dm.stats[0].item()) / B - lo) < 5e-3, it

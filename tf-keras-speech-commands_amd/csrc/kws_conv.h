@@ -27,7 +27,7 @@ struct ConvGeom {
     int KH, KW;
 };
 
-enum { EPI_NONE = 0, EPI_RELU = 1, EPI_BIAS_RELU6 = 2 };
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_BIAS_RELU6 = 2, EPI_BIAS = 3, EPI_BIAS_RELU = 4 };
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
 __host__ __device__ constexpr int stride16(int c) { return (c % 32 == 16) ? c : c + 16; }   // == 16 (mod 32)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     for (int t = 0; t < NT; ++t) {
         const int n = 16 * t + li;
         float bv = 0.f;
-        if (EPI == EPI_BIAS_RELU6) bv = bias[n];
+        if (EPI == EPI_BIAS_RELU6 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bv = bias[n];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long m = m0 + 16 * wave + 4 * lq + r;
@@ -177,6 +177,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
                 float v = acc[t][r];
                 if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
                 if (EPI == EPI_BIAS_RELU6) v = relu6f(v + bv);
+                if (EPI == EPI_BIAS) v = v + bv;
+                if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
                 dst[m * CO + n] = v;
             }
         }

@@ -12,6 +12,7 @@
 #include "kws_conv.h"
 #include "kws_layers.h"
 #include "kws_layer1.h"
+#include "kws_lite.h"
 
 using namespace kws;
 
@@ -30,6 +31,7 @@ constexpr int kMaxStatBlocks = kStatStride;
 // ---- workspace layout (simple_cnn) ---------------------------------------------------------------------------
 struct CnnWs {
     float *z[4], *a[4], *d1, *logits_unused, *loss_i, *correct_i, *dlogits, *dd1, *da4, *gz[4], *da[3];
+    float *dwo[4], *ddw[4];   // simple_cnn_lite: depthwise outputs and their gradients
     float *coef[4];     // 6*C floats per BN layer
     double *partial;    // [kMaxStatBlocks][2][256]
     size_t bytes;
@@ -47,17 +49,21 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
     const CnnDims &d = m->d;
     const size_t zs[4] = {(size_t)d.H0 * d.W0 * 16, (size_t)d.H1 * d.W1 * 32, (size_t)d.H3 * d.W3 * 64, (size_t)d.H3 * d.W3 * 128};
     const size_t as[4] = {(size_t)d.H1 * d.W1 * 16, (size_t)d.H2 * d.W2 * 32, (size_t)d.H3 * d.W3 * 64, (size_t)d.flat};
-    for (int i = 0; i < 4; ++i) { w.z[i] = take(i == 0 ? 0 : zs[i] * B); w.a[i] = take(as[i] * B); }   // z1 is never materialised (kws_layer1.h)
+    const bool lite = m->kind == KWS_SIMPLE_CNN_LITE;
+    const size_t dws[4] = {(size_t)d.H0 * d.W0 * 1, (size_t)d.H1 * d.W1 * 16, (size_t)d.H3 * d.W3 * 32, (size_t)d.H3 * d.W3 * 64};
+    for (int i = 0; i < 4; ++i) { w.z[i] = take((i == 0 && !lite) ? 0 : zs[i] * B); w.a[i] = take(as[i] * B); }   // simple_cnn never materialises z1 (kws_layer1.h)
+    for (int i = 0; i < 4; ++i) w.dwo[i] = take(lite ? dws[i] * B : 0);
     w.d1 = take((size_t)B * 128);
     w.loss_i = take(B);
     w.correct_i = take(B);
     for (int i = 0; i < 4; ++i) w.coef[i] = take(6 * 128);
-    w.partial = reinterpret_cast<double *>(take((size_t)kMaxStatBlocks * 2 * 256 * 2));
+    w.partial = reinterpret_cast<double *>(take((size_t)kMaxStatBlocks * 9 * 64 * 2));   // [9*64 or 2*C rows][kStatStride] doubles
     if (training) {
         w.dlogits = take((size_t)B * m->C);
         w.dd1 = take((size_t)B * 128);
         w.da4 = take((size_t)B * d.flat);
-        for (int i = 0; i < 4; ++i) w.gz[i] = take(i == 0 ? 0 : zs[i] * B);
+        for (int i = 0; i < 4; ++i) w.gz[i] = take((i == 0 && !lite) ? 0 : zs[i] * B);
+        for (int i = 0; i < 4; ++i) w.ddw[i] = take(lite ? dws[i] * B : 0);
         for (int i = 0; i < 3; ++i) w.da[i] = take(as[i] * B);
     }
     w.bytes = off;
@@ -283,6 +289,144 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     return KWS_OK;
 }
 
+
+// ---- simple_cnn_lite (cnn.py:77-141) --------------------------------------------------------------------------------
+ConvGeom geom1x1(int B, int H, int W)
+{
+    ConvGeom g;
+    g.B = B; g.H = H; g.W = W; g.Ho = H; g.Wo = W; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = 1; g.KW = 1;
+    return g;
+}
+
+int lite_forward(const kws_model *m, const float *feat, int B, const float *params, float *state, CnnWs &w, bool training,
+                 uint64_t seed, hipStream_t s)
+{
+    const CnnDims &d = m->d;
+    const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
+    const int Hz[4] = {d.H0, d.H1, d.H3, d.H3}, Wz[4] = {d.W0, d.W1, d.W3, d.W3};
+    const int strd[4] = {1, 1, 2, 1};
+    const bool pool[4] = {true, true, false, true};
+    const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
+    for (int l = 0; l < 4; ++l) {
+        const float *in = l == 0 ? feat : w.a[l - 1];
+        const int Cin = kCh[l], C = kCh[l + 1];
+        const long M = (long)B * Hz[l] * Wz[l];
+        const ConvGeom g = geom3x3(B, Hs[l], Ws[l], strd[l]);
+        KWS_LAUNCH(prof_name("dwconv_fwd_kernel", l + 1), dwconv_fwd_kernel, dim3(blocks_for(M * Cin, 256)), dim3(256), 0, s, in,
+                   params + m->o_dwk[l], w.dwo[l], g, Cin);
+        const float *pwk = params + m->o_pwk[l], *pwb = params + m->o_pwb[l];
+        const ConvGeom g1 = geom1x1(B, Hz[l], Wz[l]);
+        if (l == 0) KWS_LAUNCH("pw1_fwd_kernel", pw1_fwd_kernel<16>, dim3(blocks_for(M * 16, 256)), dim3(256), 0, s, w.dwo[0], pwk, pwb, w.z[0], M);
+        else if (l == 1) launch_gemm<16, 32, MODE_FWD, EPI_BIAS>(w.dwo[1], pwk, pwb, w.z[1], g1, s);
+        else if (l == 2) launch_gemm<32, 64, MODE_FWD, EPI_BIAS_RELU>(w.dwo[2], pwk, pwb, w.z[2], g1, s);      // activation='relu', cnn.py:113
+        else launch_gemm<64, 128, MODE_FWD, EPI_BIAS_RELU>(w.dwo[3], pwk, pwb, w.z[3], g1, s);                  // cnn.py:122
+        BnCoef k = coef_of(w.coef[l], C);
+        if (training) {
+            int nblk, rows;
+            stat_grid(M, C, nblk, rows);
+            KWS_LAUNCH(prof_name("channel_stats_kernel", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
+            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C,
+                       params + m->o_g[l], params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
+        } else {
+            KWS_LAUNCH(prof_name("bn_infer_coef_kernel", l + 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, C, params + m->o_g[l],
+                       params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
+        }
+        const float rate = (training && l == 3 && seed != 0) ? 0.5f : 0.f;
+        if (pool[l])
+            KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for((long)B * (Hz[l] / 2) * (Wz[l] / 2) * C, 256)),
+                       dim3(256), 0, s, w.z[l], k.scale, k.shift, w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
+        else
+            KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<false>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l],
+                       k.scale, k.shift, w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
+    }
+    ConvGeom g;
+    g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
+    launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s);
+    KWS_LAUNCH_CHECK("simple_cnn_lite forward");
+    return KWS_OK;
+}
+
+int lite_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
+                  hipEvent_t bucket_event, hipStream_t s)
+{
+    const CnnDims &d = m->d;
+    const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
+    const int Hz[4] = {d.H0, d.H1, d.H3, d.H3}, Wz[4] = {d.W0, d.W1, d.W3, d.W3};
+    const int strd[4] = {1, 1, 2, 1};
+    const bool pool[4] = {true, true, false, true};
+    const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
+    KWS_HIP_CHECK(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->P, s));
+    int rc = run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s);
+    if (rc) return rc;
+    {
+        ConvGeom g;
+        g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
+        int nblk, rows;
+        stat_grid(B, 128, nblk, rows);
+        KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
+        KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
+        launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s);
+        launch_dgrad<128, 128, 2, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
+    }
+    for (int l = 3; l >= 0; --l) {
+        const int Cin = kCh[l], C = kCh[l + 1];
+        const long M = (long)B * Hz[l] * Wz[l];
+        const float *da = l == 3 ? w.da4 : w.da[l];
+        BnCoef k = coef_of(w.coef[l], C);
+        int nblk, rows;
+        stat_grid(M, C, nblk, rows);
+        const float rate = (l == 3 && seed != 0) ? 0.5f : 0.f;
+        if (pool[l])
+            KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B,
+                       Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);
+        else
+            KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B,
+                       Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);
+        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C,
+                   params + m->o_g[l], grads + m->o_g[l], grads + m->o_b[l], k);
+        if (l >= 2)      // sepconv3 and sepconv4 carry activation='relu' (cnn.py:113,122)
+            KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<true>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l],
+                       k, params + m->o_g[l], M * C, C);
+        else
+            KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<false>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l],
+                       k, params + m->o_g[l], M * C, C);
+        // pointwise 1x1 + bias
+        const float *pwk = params + m->o_pwk[l];
+        const ConvGeom g1 = geom1x1(B, Hz[l], Wz[l]);
+        if (l == 0) {
+            KWS_LAUNCH("pw1_bwd_kernel", pw1_bwd_kernel<16>, dim3(nblk), dim3(256), 0, s, w.dwo[0], pwk, w.gz[0], w.ddw[0], M, rows, w.partial);
+            KWS_LAUNCH("partial_finalize_kernel", partial_finalize_kernel, dim3(16), dim3(256), 0, s, w.partial, nblk, 16, 0, grads + m->o_pwk[0]);
+            KWS_LAUNCH("partial_finalize_kernel", partial_finalize_kernel, dim3(16), dim3(256), 0, s, w.partial, nblk, 16, 1, grads + m->o_pwb[0]);
+        } else {
+            KWS_LAUNCH(prof_name("channel_stats_kernel.bias", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.gz[l], M, C, rows, w.partial);
+            KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, C, grads + m->o_pwb[l]);
+            if (l == 3) {
+                launch_wgrad<64, 128, 1>(w.dwo[3], w.gz[3], grads + m->o_pwk[3], g1, s);
+                launch_dgrad<128, 64, 4, 1>(w.gz[3], pwk, w.ddw[3], g1, s);
+            } else if (l == 2) {
+                launch_wgrad<32, 64, 1>(w.dwo[2], w.gz[2], grads + m->o_pwk[2], g1, s);
+                launch_dgrad<64, 32, 4, 1>(w.gz[2], pwk, w.ddw[2], g1, s);
+            } else {
+                launch_wgrad<16, 32, 1>(w.dwo[1], w.gz[1], grads + m->o_pwk[1], g1, s);
+                launch_dgrad<32, 16, 4, 1>(w.gz[1], pwk, w.ddw[1], g1, s);
+            }
+        }
+        // depthwise 3x3
+        const float *in = l == 0 ? feat : w.a[l - 1];
+        const ConvGeom g = geom3x3(B, Hs[l], Ws[l], strd[l]);
+        int nb2, rows2;
+        stat_grid(M, Cin, nb2, rows2);
+        KWS_LAUNCH(prof_name("dwconv_wgrad_kernel", l + 1), dwconv_wgrad_kernel, dim3(nb2), dim3(256), 0, s, in, w.ddw[l], g, Cin, rows2, w.partial);
+        KWS_LAUNCH("partial_finalize_kernel", partial_finalize_kernel, dim3(9 * Cin), dim3(256), 0, s, w.partial, nb2, 9 * Cin, 0, grads + m->o_dwk[l]);
+        if (l > 0)
+            KWS_LAUNCH(prof_name("dwconv_dgrad_kernel", l + 1), dwconv_dgrad_kernel, dim3(blocks_for((long)B * Hs[l] * Ws[l] * Cin, 256)), dim3(256), 0, s,
+                       w.ddw[l], params + m->o_dwk[l], w.da[l - 1], g, Cin);
+        if (l == 3 && bucket_event) KWS_HIP_CHECK(hipEventRecord(bucket_event, s));
+    }
+    KWS_LAUNCH_CHECK("simple_cnn_lite backward");
+    return KWS_OK;
+}
+
 int check_ws(const kws_model *m, int B, bool training, void *ws, size_t ws_bytes, CnnWs &w)
 {
     if (!ws) return fail(KWS_ERR_INVALID, "null workspace");
@@ -335,8 +479,7 @@ int kws_model_create(int kind, int num_classes, int n_features, int feature_size
     if (kind < KWS_SIMPLE_CNN || kind > KWS_SIMPLE_LSTM) return fail(KWS_ERR_INVALID, "Unsupported model type");   // model.py:32
     if (num_classes < 2 || num_classes > 1024) return fail(KWS_ERR_INVALID, "num_classes must be in 2..1024");
     if (n_features < 1 || feature_size < 1) return fail(KWS_ERR_INVALID, "bad input geometry");
-    if (kind != KWS_SIMPLE_CNN && kind != KWS_SIMPLE_GRU)
-        return fail(KWS_ERR_UNSUPPORTED, "only simple_cnn and simple_gru have HIP kernels so far");
+    if (kind == KWS_SIMPLE_LSTM) return fail(KWS_ERR_UNSUPPORTED, "simple_lstm has no HIP kernels yet");
     auto *m = new kws_model();
     m->kind = kind; m->C = num_classes; m->n_features = n_features; m->feature_size = feature_size;
     if (kind == KWS_SIMPLE_GRU) {
@@ -366,9 +509,17 @@ int kws_model_create(int kind, int num_classes, int n_features, int feature_size
         return fail(KWS_ERR_INVALID, "input %dx%d is too small for simple_cnn", n_features, feature_size);
     }
     const char *cn[4] = {"conv2d", "conv2d_1", "conv2d_2", "conv2d_3"};
+    const char *sn[4] = {"separable_conv2d", "separable_conv2d_1", "separable_conv2d_2", "separable_conv2d_3"};
     const char *bn[4] = {"batch_normalization", "batch_normalization_1", "batch_normalization_2", "batch_normalization_3"};
     for (int l = 0; l < 4; ++l) {
-        m->o_k[l] = m->add(std::string(cn[l]) + "/kernel", {3, 3, kCh[l], kCh[l + 1]}, true);
+        if (kind == KWS_SIMPLE_CNN_LITE) {
+            m->o_dwk[l] = m->add(std::string(sn[l]) + "/depthwise_kernel", {3, 3, kCh[l], 1}, true);
+            m->o_pwk[l] = m->add(std::string(sn[l]) + "/pointwise_kernel", {1, 1, kCh[l], kCh[l + 1]}, true);
+            m->o_pwb[l] = m->add(std::string(sn[l]) + "/bias", {kCh[l + 1]}, true);
+            m->o_k[l] = m->o_dwk[l];
+        } else {
+            m->o_k[l] = m->add(std::string(cn[l]) + "/kernel", {3, 3, kCh[l], kCh[l + 1]}, true);
+        }
         m->o_g[l] = m->add(std::string(bn[l]) + "/gamma", {kCh[l + 1]}, true);
         m->o_b[l] = m->add(std::string(bn[l]) + "/beta", {kCh[l + 1]}, true);
         m->o_mm[l] = m->add(std::string(bn[l]) + "/moving_mean", {kCh[l + 1]}, false);
@@ -419,7 +570,8 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
     int rc = check_ws(m, B, false, ws, ws_bytes, w);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = cnn_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s);
+    rc = m->kind == KWS_SIMPLE_CNN_LITE ? lite_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s)
+                                        : cnn_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s);
     if (rc) return rc;
     return run_head(m, B, params, w.d1, w.loss_i, w.correct_i, nullptr, nullptr, probs, argmax, nullptr, 0.f, nullptr, 0, s);
 }
@@ -433,16 +585,22 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     int rc = check_ws(m, a->B, true, a->ws, a->ws_bytes, w);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    rc = cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s);
+    const bool lite = m->kind == KWS_SIMPLE_CNN_LITE;
+    rc = lite ? lite_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s)
+              : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s);
     if (rc) return rc;
     // Keras reduces the per-sample losses with a batch mean (train.py:75-77): d(mean)/d(logits) carries 1/B
     rc = run_head(m, a->B, a->params, w.d1, w.loss_i, w.correct_i, a->labels, a->class_weights, a->probs, nullptr, w.dlogits,
                   a->grad_scale / (float)a->B, a->stats, a->ignore_index, s);
     if (rc) return rc;
-    return cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s);
+    return lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
+                : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s);
 }
 
-int64_t kws_model_grad_split(const kws_model *m) { return !m ? 0 : (m->kind == KWS_SIMPLE_CNN ? m->o_k[3] : 0); }
+int64_t kws_model_grad_split(const kws_model *m)
+{
+    return !m ? 0 : ((m->kind == KWS_SIMPLE_CNN || m->kind == KWS_SIMPLE_CNN_LITE) ? m->o_k[3] : 0);
+}
 
 int kws_loss_forward(const float *y_pred, const int32_t *labels, const float *class_weights, int from_logits,
                      int ignore_index, int B, int C, float *losses, void *stream)

@@ -43,6 +43,8 @@ struct kws_model {
     kws::CnnDims d{};
     // simple_cnn offsets into params / state
     int64_t o_k[4], o_g[4], o_b[4], o_dk, o_db, o_mm[4], o_mv[4];
+    // simple_cnn_lite: depthwise / pointwise kernels and pointwise bias of the four SeparableConv2D stages
+    int64_t o_dwk[4], o_pwk[4], o_pwb[4];
     // simple_gru offsets
     int64_t o_rk, o_ru, o_rb;
     // head (all models): Dense(C) on a K-wide feature vector

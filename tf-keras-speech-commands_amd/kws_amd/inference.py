@@ -1,0 +1,41 @@
+"""Graph-captured inference: featurize + forward replayed as ONE hipGraph (BASELINE.json configs[4] structure).
+
+The capture goes through torch.cuda.CUDAGraph on a side stream: every kernel the C ABI enqueues on torch's current
+stream (kws_featurize, kws_model_forward) becomes a graph node, so a replay costs one launch instead of ~25."""
+from . import lib as _l
+
+
+class InferenceSession(object):
+    """Static-shape streaming inference: copy (or write) a batch into `self.wav`, call run(), read `self.probs`/`argmax`."""
+
+    def __init__(self, device_model, featurizer, batch, samples=None, wav_dtype=None, use_graph=True):
+        import torch
+        if not torch.cuda.is_available():
+            raise _l.KwsError(-3, "no HIP device: inference has no CPU fallback")
+        self.dm, self.feat, self.batch = device_model, featurizer, int(batch)
+        g = featurizer.geometry
+        samples = int(samples or g["max_samples"])
+        wav_dtype = wav_dtype or torch.float32
+        dev = device_model.device
+        self.wav = torch.zeros((self.batch, samples), dtype=wav_dtype, device=dev)
+        self.features = torch.empty((self.batch, g["n_features"], g["feature_size"]), dtype=torch.float32, device=dev)
+        self.probs = self.argmax = None
+        self._graph = None
+        self._eager()                                   # warm-up: allocations (workspace, outputs) happen outside the capture
+        torch.cuda.synchronize()
+        if use_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._eager()
+            self._graph = graph
+
+    def _eager(self):
+        self.feat(self.wav, out=self.features)
+        self.probs, self.argmax = self.dm.forward(self.features)
+
+    def run(self):
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._eager()
+        return self.probs, self.argmax

@@ -1,0 +1,26 @@
+import sys, os
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tf-keras-speech-commands_amd"))
+import numpy as np, torch
+from classifier.params import pr
+from kws_amd.featurizer import Featurizer
+from kws_amd.inference import InferenceSession
+from kws_amd.init import init_weights
+from kws_amd.model import DeviceModel, ModelSpec
+feat = Featurizer(pr)
+for mt, B in (("simple_cnn_lite", 16384), ("simple_cnn", 4096), ("simple_gru", 16384)):
+    spec = ModelSpec(mt, 36, 30, 20); dm = DeviceModel(spec); dm.set_weights(init_weights(spec, 0))
+    for graph in (False, True):
+        s = InferenceSession(dm, feat, B, use_graph=graph)
+        s.wav.copy_(0.1 * torch.randn((B, 16000), device="cuda"))
+        for _ in range(3): s.run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): s.run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        p1 = s.probs.clone()
+        print("%-16s B=%5d graph=%-5s %.3f ms  %.2f Mclips/s  (%.1f%% of the 8 TB/s roofline at 64144 B/clip)" % (mt, B, graph, ms, B / ms / 1e3, B / ms / 1e3 * 64144 / 8e6 * 100))
+    eager = InferenceSession(dm, feat, B, use_graph=False); eager.wav.copy_(s.wav); eager.run()
+    print("   graph == eager:", torch.equal(eager.probs, p1))

@@ -187,8 +187,16 @@ def main():
             ach, peak, unit = amount / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
         else:
             ach, peak, unit = amount / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        traffic = None       # HBM bytes per launch from the PMC passes recorded in profiles/ (bench.py cannot run rocprofv3 itself)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                rec = json.load(f).get(name)
+            if rec and rec.get("batch") == B:
+                traffic = rec["traffic_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         roofline = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(avg_ms, 5),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
                     "share_of_step_kernel_time": round(rep[name]["total_ms"] / tot, 3)}
 
     cpu = None

@@ -291,3 +291,36 @@ def test_lite_multi_step_training_tracks_oracle(torch):
         # one weight differs by exactly 2*lr after step 0 while every gradient matches to 3e-4).  simple_cnn, which has no
         # such direction, tracks the oracle to 1e-7 with the same code.  Hence 5e-3 here instead of 1e-3.
         assert abs(float(dm.stats[0].item()) / B - lo) < 5e-3, it
+
+
+def test_cnn_full_batch_4096_grids(torch):
+    """B = 4096 (BASELINE size) exercises launch grids the small-batch parity tests never reach.  First a 512-clip batch
+    against the float64 oracle; then, at 4096, invariants that hold exactly up to float-atomic ordering: the loss and every
+    gradient tensor are unchanged when the clips of the batch are permuted, all gradients are finite and non-zero."""
+    from oracle import model_oracle as mo
+    C = 36
+    om, dm = build("simple_cnn", C)
+    B = 512
+    x = features(B, 41)
+    y = np.random.default_rng(42).integers(0, C, B)
+    loss, acc, _ = mo.train_forward_backward(om, x.astype(np.float64), y)
+    dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda())
+    assert abs(float(dm.stats[0].item()) / B - loss) < 1e-4
+    for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
+        assert rel_err(g, want) < 1e-3, (li, n, rel_err(g, want))   # fp32 sums over 512*600 terms per conv1 weight
+    B = 4096
+    x = features(B, 43)
+    y = np.random.default_rng(44).integers(0, C, B).astype(np.int32)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    dm.train_fwd_bwd(xt, yt)
+    g1 = [g.copy() for g in dm.get_grads()]
+    l1 = float(dm.stats[0].item())
+    perm = torch.randperm(B, device="cuda")
+    dm.train_fwd_bwd(xt[perm].contiguous(), yt[perm].contiguous())
+    g2 = dm.get_grads()
+    assert abs(l1 - float(dm.stats[0].item())) < 1e-3 * abs(l1)
+    for a, b2, t in zip(g1, g2, [t for t in dm.spec.tensors if t["trainable"]]):
+        assert np.all(np.isfinite(a)) and np.abs(a).max() > 0, t["name"]
+        assert rel_err(b2, a) < 1e-4, (t["name"], rel_err(b2, a))
+    # and against a fresh single-GPU "two halves" estimate: the head/dense gradients of a 4096 batch are NOT the mean of
+    # two 2048 halves (BatchNormalization couples the clips), so no such check is made here.

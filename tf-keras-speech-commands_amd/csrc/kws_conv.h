@@ -275,11 +275,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     }
 }
 
+// N consecutive floats with the widest aligned load (N = 1, 2, 4, 8); p must be N*4-byte aligned (16 for N = 8)
+template <int N>
+__device__ __forceinline__ void load_vec(const float *__restrict__ p, float (&v)[N])
+{
+    if constexpr (N == 1) {
+        v[0] = p[0];
+    } else if constexpr (N == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        v[0] = t.x; v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            const float4 t = *reinterpret_cast<const float4 *>(p + 4 * i);
+            v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // WGRAD, LDS-free: every MFMA fragment comes straight from global memory.
 //   A^T fragment (row = input channel, k = pixel): lane (li, lq) reads x[pix(p0+lq) + tap][cb + 16 mt + li]
 //   B   fragment (k = pixel, col = out channel):   lane (li, lq) reads dz[p0+lq][16 nt + li]
-// i.e. four 64-byte segments per load; the GPB taps of a block re-touch the same lines (L1/L2 hits).  Each wave owns a
+// The texture addresser spends ~16 cycles on a wave load whatever its width, so the 16x16 tiles use a PERMUTED channel
+// map: M-tile e holds input channels cb + MT*row + e and N-tile e holds output channels NT*col + e; a lane then fetches
+// its MT (resp. NT) fragments with ONE vector load of consecutive channels.  The GPB taps of a block re-touch the same
+// lines (L1/L2 hits).  Each wave owns a
 // contiguous range of 4-pixel steps and ALL GPB*MT*NT output tiles of the block (A fragments are reused across NT,
 // B fragments across GPB*MT), so there is no staging, no barrier and one LDS reduction + one atomic set per block.
 // ---------------------------------------------------------------------------------------------------------------
@@ -328,17 +349,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
     auto load_frags = [&](float (&af)[GPB][MT], float (&bf)[NT]) {
         // out-of-range pixels / padding taps read the zero page: no op touches a loaded value before its MFMA
         const bool pok = p < M;
-        const float *dzp = pok ? dz + ((int)p * COUT + li) : zeros + li;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = dzp[16 * nt];
+        load_vec<NT>(pok ? dz + ((int)p * COUT + NT * li) : zeros + NT * li, bf);
         const int y0 = oh * g.stride - g.pt, x0 = ow * g.stride - g.pl;
-        const int base = ((b * g.H + y0) * g.W + x0) * CIN + li;      // may point into the halo; used only when in range
+        const int base = ((b * g.H + y0) * g.W + x0) * CIN + MT * li;  // may point into the halo; used only when in range
 #pragma unroll
         for (int gi = 0; gi < GPB; ++gi) {
             const bool ok = pok && gok[gi] && (unsigned)(y0 + kh[gi]) < (unsigned)g.H && (unsigned)(x0 + kw[gi]) < (unsigned)g.W;
-            const float *xp = ok ? x + (base + toff[gi]) : zeros + li;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[gi][mt] = xp[16 * mt];
+            load_vec<MT>(ok ? x + (base + toff[gi]) : zeros + MT * li, af[gi]);
         }
         p += 4;
         ow += 4;
@@ -366,29 +383,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
                 for (int nt = 0; nt < NT; ++nt) acc[gi][mt][nt] = mfma16(af[gi][mt], bf[nt], acc[gi][mt][nt]);
     }
 
-    // reduce the 4 waves' partial tiles through LDS, one tile at a time, then add to global memory
+    // Reduce the 4 waves' partial tiles through LDS and gather each (group, M-tile) block as 16 full rows of COUT
+    // contiguous output channels (the permuted N-tiles interleave), so every atomic wave-instruction adds 64 contiguous
+    // floats -- strided float atomics run ~10x slower (MI355X_MICROARCH.md, Global float atomics).
+    float *rowblk = red + 4 * 64 * 4;                                 // [16][COUT]
 #pragma unroll
     for (int gi = 0; gi < GPB; ++gi)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 __syncthreads();
                 *reinterpret_cast<f32x4 *>(&red[(wave * 64 + lane) * 4]) = acc[gi][mt][nt];
                 __syncthreads();
-                if (wave == 0 && gok[gi]) {
+                if (wave == 0) {
                     const f32x4 a0 = *reinterpret_cast<const f32x4 *>(&red[(0 * 64 + lane) * 4]);
                     const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&red[(1 * 64 + lane) * 4]);
                     const f32x4 a2 = *reinterpret_cast<const f32x4 *>(&red[(2 * 64 + lane) * 4]);
                     const f32x4 a3 = *reinterpret_cast<const f32x4 *>(&red[(3 * 64 + lane) * 4]);
-                    const int tap = (grp0 + gi) / CBLK;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ci = cb[gi] + 16 * mt + 4 * lq + r, co = 16 * nt + li;
-                        atomicAdd(dw + ((long)(tap * CIN + ci)) * COUT + co, (a0[r] + a1[r]) + (a2[r] + a3[r]));
-                    }
+                    for (int r = 0; r < 4; ++r) rowblk[(4 * lq + r) * COUT + NT * li + nt] = (a0[r] + a1[r]) + (a2[r] + a3[r]);
                 }
             }
+            __syncthreads();
+            if (gok[gi]) {
+                const int tap = (grp0 + gi) / CBLK;
+                for (int idx = threadIdx.x; idx < 16 * COUT; idx += 256) {
+                    const int row = idx / COUT, co = idx % COUT;
+                    atomicAdd(dw + ((long)(tap * CIN + cb[gi] + MT * row + mt)) * COUT + co, rowblk[idx]);
+                }
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -103,7 +103,7 @@ void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g,
     const int spw = (int)((steps + waves - 1) / waves);
     const long gx = (steps + 4L * spw - 1) / (4L * spw);
     static const std::string name = "conv_wgrad<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
-    KWS_LAUNCH(name.c_str(), (conv_wgrad_direct_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 4 * 64 * 4 * sizeof(float),
+    KWS_LAUNCH(name.c_str(), (conv_wgrad_direct_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), (4 * 64 * 4 + 16 * COUT) * sizeof(float),
                s, x, dz, dw, zero_page(), g, spw);
 }
 
@@ -213,6 +213,16 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
 
     KWS_HIP_CHECK(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->P, s));
+    // The weight-gradient GEMM of a layer only READS (x, dz) and adds into grads; the data-gradient GEMM and the next
+    // layer's BN backward do not depend on it.  Each of them alone leaves the MFMA pipe more than half idle, so wgrad runs
+    // on the library's side stream (fork after dz is final, one join at the end) and shares the chip with the main chain.
+    hipStream_t s2 = side_stream();
+    if (!s2) return fail(KWS_ERR_HIP, "cannot create the internal side stream");
+    auto fork = [&](int ev) -> int {          // side stream waits for everything enqueued on s so far
+        KWS_HIP_CHECK(hipEventRecord(sync_event(ev), s));
+        KWS_HIP_CHECK(hipStreamWaitEvent(s2, sync_event(ev), 0));
+        return KWS_OK;
+    };
     // head: dW2, db2, dd1 (gated by dense's ReLU6)
     {
         const int rc = run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s);
@@ -222,11 +232,12 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     {
         ConvGeom g;
         g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
+        if (int rc = fork(0)) return rc;
+        launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s2);
         int nblk, rows;
         stat_grid(B, 128, nblk, rows);
         KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
         KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
-        launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s);
         launch_dgrad<128, 128, 2, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
     }
     for (int l = 3; l >= 1; --l) {
@@ -240,34 +251,39 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         const float rate = (l == 3 && seed != 0) ? 0.5f : 0.f;
         if (pool[l])
             KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
-                               rows, w.partial, rate, slo, shi);
+                       rows, w.partial, rate, slo, shi);
         else
             KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
-                               rows, w.partial, rate, slo, shi);
+                       rows, w.partial, rate, slo, shi);
         KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
-                           grads + m->o_g[l], grads + m->o_b[l], k);
+                   grads + m->o_g[l], grads + m->o_b[l], k);
         if (l == 3)
             KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<true>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
-                               params + m->o_g[l], M * C, C);
+                       params + m->o_g[l], M * C, C);
         else
             KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<false>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
-                               params + m->o_g[l], M * C, C);
-        const float *in = l == 0 ? feat : w.a[l - 1];
+                       params + m->o_g[l], M * C, C);
+        const float *in = w.a[l - 1];
         float *dk = grads + m->o_k[l];
         const float *kern = params + m->o_k[l];
+        if (int rc = fork(l)) return rc;                       // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
-            launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s);
-            // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final from here on
-            if (bucket_event) KWS_HIP_CHECK(hipEventRecord(bucket_event, s));
+            launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);
+            if (bucket_event) {
+                // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here
+                KWS_HIP_CHECK(hipEventRecord(sync_event(8), s2));
+                KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(8), 0));
+                KWS_HIP_CHECK(hipEventRecord(bucket_event, s));
+            }
             launch_dgrad<128, 64, 4, 1>(w.gz[3], kern, w.da[2], g, s);
         } else if (l == 2) {
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
-            launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s);
+            launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2);
             launch_dgrad<64, 32, 4, 2>(w.gz[2], kern, w.da[1], g, s);
-        } else if (l == 1) {
+        } else {
             const ConvGeom g = geom3x3(B, Hs[1], Ws[1], 1);
-            launch_wgrad<16, 32, 9>(in, w.gz[1], dk, g, s);
+            launch_wgrad<16, 32, 9>(in, w.gz[1], dk, g, s2);
             launch_dgrad<32, 16, 4, 1>(w.gz[1], kern, w.da[0], g, s);
         }
     }
@@ -285,6 +301,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         KWS_LAUNCH("l1_bwd_wgrad_kernel", l1_bwd_wgrad_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
                    grads + m->o_k[0], B, d.H0, d.W0, cpb);
     }
+    KWS_HIP_CHECK(hipEventRecord(sync_event(9), s2));             // join: every wgrad is part of the caller's stream order again
+    KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(9), 0));
     KWS_LAUNCH_CHECK("simple_cnn backward");
     return KWS_OK;
 }

@@ -51,18 +51,21 @@ def kernel_models(B, C):
     a = [15 * 10 * 16, 7 * 5 * 32, 4 * 3 * 64, 256]                    # activations per clip
     m = {}
     m["featurize_fft1024_f32"] = ("hbm", B * 66400.0)                   # 64000 in + 2400 out
-    m["conv1_fwd_kernel"] = ("hbm", B * (600 + z[0]) * f)
-    m["conv1_wgrad_kernel"] = ("hbm", B * (600 + z[0]) * f)
+    # layer 1 is recomputed from the feature map (kws_layer1.h): bytes = features (+ a1 / da1), never a z1-sized tensor
+    m["l1_stats_kernel"] = ("hbm", B * 600.0 * f)
+    m["l1_act_pool_kernel"] = ("hbm", B * (600 + a[0]) * f)
+    m["l1_bwd_reduce_kernel"] = ("hbm", B * (600 + a[0]) * f)
+    m["l1_bwd_wgrad_kernel"] = ("hbm", B * (600 + a[0]) * f)
     convs = {"16,32": (150, 9 * 16 * 32), "32,64": (12, 9 * 32 * 64), "64,128": (12, 9 * 64 * 128), "128,128": (1, 256 * 128)}
     for k, (pix, kn) in convs.items():
         m["conv_gemm_fwd<%s>" % k] = ("mfma", 2.0 * B * pix * kn)
         m["conv_wgrad<%s>" % k] = ("mfma", 2.0 * B * pix * kn)
-    # dgrad as launched: every tap is multiplied (stride-2 zeros included); algorithmic = the useful MACs
-    m["conv_gemm_dgrad<32,16>"] = ("mfma", 2.0 * B * 150 * 9 * 16 * 32)
-    m["conv_gemm_dgrad<64,32>"] = ("mfma", 2.0 * B * 12 * 9 * 32 * 64)
-    m["conv_gemm_dgrad<128,64>"] = ("mfma", 2.0 * B * 12 * 9 * 64 * 128)
-    m["conv_gemm_dgrad<128,128>"] = ("mfma", 2.0 * B * 256 * 128)
-    for l in range(4):
+    # dgrad kernels are named <reduced channels, produced channels>; algorithmic = the useful MACs of the layer
+    m["conv_dgrad<32,16>"] = ("mfma", 2.0 * B * 150 * 9 * 16 * 32)
+    m["conv_dgrad<64,32>"] = ("mfma", 2.0 * B * 12 * 9 * 32 * 64 / 4)     # four launches per step (stride-2 parity classes)
+    m["conv_dgrad<128,64>"] = ("mfma", 2.0 * B * 12 * 9 * 64 * 128)
+    m["conv_dgrad<128,128>"] = ("mfma", 2.0 * B * 256 * 128)
+    for l in range(1, 4):
         L = ".L%d" % (l + 1)
         m["channel_stats_kernel" + L] = ("hbm", B * z[l] * f)
         m["bn_act_pool_kernel" + L] = ("hbm", B * (z[l] + a[l]) * f)

@@ -7,14 +7,12 @@
 //   WGRAD  dW[tap][c][n] = sum_m   x[pix(m)+tap][c]      * dz[m][n]
 // fp32 MFMA is bit-exact fp32 (a k-ordered fmaf chain), so parity with the fp32/fp64 oracle needs no extra slack.
 //
-// Tiling (one 256-thread block = 4 waves):
-//   FWD/DGRAD: 64 rows x all CO columns per block; wave w owns rows 16w..16w+15 and CO/16 accumulator tiles.  The K
-//              loop walks (tap, KC-channel chunk); the A tile (64 x KC, gathered rows, zero for padding) and the
-//              B tile (KC x CO) are staged through LDS with the next chunk's global loads in flight during the MFMAs.
-//   WGRAD:     the block owns a pixel range and a group of taps; per 64-pixel step it stages dz (64 x COUT) and the
-//              tap-shifted x tiles, the 16x16 output tiles are dealt round-robin to the 4 waves, and the partial dW
-//              is added to global memory with float atomics (the pixel range is split over many blocks).
-// LDS strides are chosen so that every half-wave ds_read_b32 of a fragment is bank-conflict free
+// Three kernels:
+//   conv_gemm_kernel         FWD: 64 rows x all CO columns per block, A (gathered rows) and B (weights) tiles staged
+//                            through LDS with the next chunk's global loads in flight during the MFMAs
+//   conv_dgrad_direct_kernel DGRAD, LDS-free: float4 fragments straight from global memory, one launch per stride class
+//   conv_wgrad_direct_kernel WGRAD, LDS-free: vector fragments with permuted tile maps, float atomics into grads
+// LDS strides of the FWD kernel keep every half-wave ds_read_b32 of a fragment bank-conflict free
 // (row stride == 2 mod 32 words for A[row][k], == 16 mod 32 for [k][col] tiles).
 #pragma once
 #include "kws_device.h"
@@ -33,7 +31,7 @@ enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 __host__ __device__ constexpr int stride16(int c) { return (c % 32 == 16) ? c : c + 16; }   // == 16 (mod 32)
 
 // ---------------------------------------------------------------------------------------------------------------
-// FWD / DGRAD.  CR = channels reduced per tap, CO = channels produced.
+// FWD.  CR = channels reduced per tap, CO = channels produced.
 // ---------------------------------------------------------------------------------------------------------------
 template <int CR, int CO, int MODE, int EPI>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict__ src, const float *__restrict__ wgt,
@@ -50,14 +48,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     constexpr int NB = (BUNITS + 255) / 256;
     constexpr int CPT = CR / KC;               // chunks per tap
     static_assert(CR % KC == 0 && CO % 16 == 0 && KC % 4 == 0, "channel counts must be multiples of 16");
+    static_assert(MODE == MODE_FWD, "the data-gradient product has its own kernel (conv_dgrad_direct_kernel)");
 
     __shared__ __attribute__((aligned(16))) float As[64 * SA];
     __shared__ __attribute__((aligned(16))) float Bs[KC * SB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-    // rows of this GEMM: output pixels (FWD) or input pixels (DGRAD)
-    const int RH = MODE == MODE_FWD ? g.Ho : g.H, RW = MODE == MODE_FWD ? g.Wo : g.W;
-    const int SH = MODE == MODE_FWD ? g.H : g.Ho, SW = MODE == MODE_FWD ? g.W : g.Wo;   // source spatial size
+    const int RH = g.Ho, RW = g.Wo;      // rows of this GEMM: output pixels
+    const int SH = g.H, SW = g.W;        // source spatial size
     const long M = (long)g.B * RH * RW;
     const long m0 = (long)blockIdx.x * 64;
     const int ntaps = g.KH * g.KW, nchunks = ntaps * CPT;
@@ -88,17 +86,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
         for (int j = 0; j < NA; ++j) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a_b[j] >= 0) {
-                int sy, sx;
-                bool ok;
-                if (MODE == MODE_FWD) {
-                    sy = a_y[j] * g.stride + kh - g.pt;
-                    sx = a_x[j] * g.stride + kw - g.pl;
-                    ok = sy >= 0 && sy < SH && sx >= 0 && sx < SW;
-                } else {
-                    const int ty = a_y[j] + g.pt - kh, tx = a_x[j] + g.pl - kw;
-                    sy = ty / g.stride; sx = tx / g.stride;
-                    ok = ty >= 0 && tx >= 0 && ty % g.stride == 0 && tx % g.stride == 0 && sy < SH && sx < SW;
-                }
+                const int sy = a_y[j] * g.stride + kh - g.pt, sx = a_x[j] * g.stride + kw - g.pl;
+                const bool ok = sy >= 0 && sy < SH && sx >= 0 && sx < SW;
                 if (ok) v = *reinterpret_cast<const float4 *>(src + (((long)a_b[j] * SH + sy) * SW + sx) * CR + c0 + a_c4[j] * 4);
             }
             ra[j] = v;
@@ -108,13 +97,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
             const int u = tid + 256 * j;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (u < BUNITS) {
-                if (MODE == MODE_FWD) {
-                    const int kk = u / (CO / 4), n4 = u % (CO / 4);
-                    v = *reinterpret_cast<const float4 *>(wgt + ((long)(tap * CR + c0 + kk)) * CO + n4 * 4);
-                } else {
-                    const int n = u / A4, k4 = u % A4;    // W[tap][n][c0 + 4*k4 ..]: HWIO with I = CO, O = CR
-                    v = *reinterpret_cast<const float4 *>(wgt + ((long)(tap * CO + n)) * CR + c0 + k4 * 4);
-                }
+                const int kk = u / (CO / 4), n4 = u % (CO / 4);
+                v = *reinterpret_cast<const float4 *>(wgt + ((long)(tap * CR + c0 + kk)) * CO + n4 * 4);
             }
             rb[j] = v;
         }
@@ -133,16 +117,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
         for (int j = 0; j < NB; ++j) {
             const int u = tid + 256 * j;
             if (u < BUNITS) {
-                if (MODE == MODE_FWD) {
-                    const int kk = u / (CO / 4), n4 = u % (CO / 4);
-                    *reinterpret_cast<float4 *>(&Bs[kk * SB + n4 * 4]) = rb[j];
-                } else {
-                    const int n = u / A4, k4 = u % A4;
-                    Bs[(k4 * 4 + 0) * SB + n] = rb[j].x;
-                    Bs[(k4 * 4 + 1) * SB + n] = rb[j].y;
-                    Bs[(k4 * 4 + 2) * SB + n] = rb[j].z;
-                    Bs[(k4 * 4 + 3) * SB + n] = rb[j].w;
-                }
+                const int kk = u / (CO / 4), n4 = u % (CO / 4);
+                *reinterpret_cast<float4 *>(&Bs[kk * SB + n4 * 4]) = rb[j];
             }
         }
     };
@@ -180,96 +156,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
                 if (EPI == EPI_BIAS) v = v + bv;
                 if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
                 dst[m * CO + n] = v;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// WGRAD.  CB = min(CIN, 64) input channels per k-group; a block owns GPB consecutive (tap, channel-block) groups.
-// ---------------------------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int GPB>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
-                                                          float *__restrict__ dw, ConvGeom g, int steps_per_block)
-{
-    constexpr int CB = CIN >= 64 ? 64 : CIN;
-    constexpr int CBLK = CIN / CB;             // channel blocks per tap
-    constexpr int SX = stride16(CB), SD = stride16(COUT);
-    constexpr int MT = CB / 16, NT = COUT / 16;
-    constexpr int T = GPB * MT * NT;           // 16x16 output tiles owned by the block
-    constexpr int TPW = (T + 3) / 4;           // tiles per wave
-    constexpr int X4 = CB / 4, D4 = COUT / 4;
-    static_assert(CIN % CB == 0 && CB % 16 == 0 && COUT % 16 == 0, "channel counts must be multiples of 16");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Ds = smem;                          // [64][SD]
-    float *Xs = smem + 64 * SD;                // [GPB][64][SX]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
-    const long M = (long)g.B * g.Ho * g.Wo;
-    const int ngroups = g.KH * g.KW * CBLK;
-    const int grp0 = blockIdx.y * GPB;
-    const long mbeg = (long)blockIdx.x * steps_per_block * 64;
-
-    f32x4 acc[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int step = 0; step < steps_per_block; ++step) {
-        const long ms = mbeg + (long)step * 64;
-        if (ms >= M) break;
-        __syncthreads();                       // previous step's MFMAs are done with the tiles
-        for (int u = tid; u < 64 * D4; u += 256) {
-            const int row = u / D4, c4 = u % D4;
-            const long m = ms + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < M) v = *reinterpret_cast<const float4 *>(dz + m * COUT + c4 * 4);
-            *reinterpret_cast<float4 *>(&Ds[row * SD + c4 * 4]) = v;
-        }
-        for (int u = tid; u < GPB * 64 * X4; u += 256) {
-            const int gi = u / (64 * X4), rem = u % (64 * X4), row = rem / X4, c4 = rem % X4;
-            const int grp = grp0 + gi;
-            const long m = ms + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grp < ngroups && m < M) {
-                const int tap = grp / CBLK, cb = (grp % CBLK) * CB;
-                const int kh = tap / g.KW, kw = tap % g.KW;
-                const int pix = (int)(m % ((long)g.Ho * g.Wo)), b = (int)(m / ((long)g.Ho * g.Wo));
-                const int sy = (pix / g.Wo) * g.stride + kh - g.pt, sx = (pix % g.Wo) * g.stride + kw - g.pl;
-                if (sy >= 0 && sy < g.H && sx >= 0 && sx < g.W)
-                    v = *reinterpret_cast<const float4 *>(x + (((long)b * g.H + sy) * g.W + sx) * CIN + cb + c4 * 4);
-            }
-            *reinterpret_cast<float4 *>(&Xs[(gi * 64 + row) * SX + c4 * 4]) = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mm = 0; mm < 64; mm += 4) {
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int tile = wave + 4 * t;
-                if (tile < T) {
-                    const int gi = tile / (MT * NT), mt = (tile / NT) % MT, nt = tile % NT;
-                    const float a = Xs[(gi * 64 + mm + lq) * SX + 16 * mt + li];   // A^T: row = channel, k = pixel
-                    const float bv = Ds[(mm + lq) * SD + 16 * nt + li];
-                    acc[t] = mfma16(a, bv, acc[t]);
-                }
-            }
-        }
-    }
-
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tile = wave + 4 * t;
-        if (tile < T) {
-            const int gi = tile / (MT * NT), mt = (tile / NT) % MT, nt = tile % NT;
-            const int grp = grp0 + gi;
-            if (grp < ngroups) {
-                const int tap = grp / CBLK, cb = (grp % CBLK) * CB;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ci = cb + 16 * mt + 4 * lq + r, co = 16 * nt + li;
-                    atomicAdd(dw + ((long)(tap * CIN + ci)) * COUT + co, acc[t][r]);
-                }
             }
         }
     }
@@ -562,13 +448,6 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__r
                 for (int nt = 0; nt < NT; ++nt) o[16 * nt] = acc[mt][nt][r];
             }
         }
-}
-
-template <int CIN, int COUT, int GPB>
-constexpr size_t conv_wgrad_smem()
-{
-    constexpr int CB = CIN >= 64 ? 64 : CIN;
-    return sizeof(float) * (size_t)(64 * stride16(COUT) + GPB * 64 * stride16(CB));
 }
 
 }  // namespace kws

@@ -1,5 +1,5 @@
 // csrc/kws_layers.h -- the non-GEMM kernels of the train / inference step (gfx950).
-//   conv1 (Cin = 1) direct kernels, BatchNormalization statistics / apply / backward, ReLU6 + 2x2 max-pool,
+//   BatchNormalization statistics / apply / backward, ReLU6 + 2x2 max-pool (layer 1 has fused variants in kws_layer1.h),
 //   inverted dropout, the softmax head with the reference's two losses, and the Keras-form Adam update.
 // Reference semantics: classifier/models/cnn.py:27-66, classifier/loss.py:21-77, common/model_utils.py:47 and the
 // Keras layer defaults listed in SURVEY.md section 7.
@@ -28,89 +28,6 @@ __device__ __forceinline__ double block_sum_partials(const double *__restrict__ 
     s = sh[0];
     __syncthreads();
     return s;
-}
-
-// ---- conv1: 3x3 'same', Cin = 1 -> COUT (cnn.py:27-31) --------------------------------------------------------
-template <int COUT>
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
-                                                         float *__restrict__ z, int B, int H, int W)
-{
-    __shared__ float ws[9 * COUT];
-    for (int i = threadIdx.x; i < 9 * COUT; i += 256) ws[i] = w[i];
-    __syncthreads();
-    const long M = (long)B * H * W, m = (long)blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
-    const int pix = (int)(m % (H * W)), b = (int)(m / (H * W)), oh = pix / W, ow = pix % W;
-    float v[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int ih = oh + t / 3 - 1, iw = ow + t % 3 - 1;
-        v[t] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? x[((long)b * H + ih) * W + iw] : 0.f;
-    }
-    float4 *dst = reinterpret_cast<float4 *>(z + m * COUT);
-#pragma unroll
-    for (int c4 = 0; c4 < COUT / 4; ++c4) {
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaf(v[t], ws[t * COUT + c4 * 4 + e], o[e]);
-        dst[c4] = make_float4(o[0], o[1], o[2], o[3]);
-    }
-}
-
-// dW[tap][co] = sum_m x[pix(m)+tap] * dz[m][co] on the MFMA: a 16x16 tile (taps padded 9 -> 16, co = 16) per wave,
-// reduction index = pixel.  Each wave walks whole clips: the clip's (H+2)x(W+2) zero-haloed input sits in the wave's
-// LDS slice (A fragments = shifted reads of it), dz fragments are read straight from global memory (4 pixels x 16
-// channels = 256 contiguous bytes per MFMA).  Block partials are combined in LDS and added with 144 atomics.
-__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dz,
-                                                           float *__restrict__ dw, int B, int H, int W, int clips_per_wave)
-{
-    extern __shared__ float c1s[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
-    const int HP = H + 2, WP = W + 2, HW = H * W;
-    float *xs = c1s + wave * HP * WP;
-    const int kh = li / 3, kw = li % 3;
-    const bool tap_ok = li < 9;
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int b0 = (blockIdx.x * 4 + wave) * clips_per_wave;
-    for (int cb = 0; cb < clips_per_wave; ++cb) {
-        const int b = b0 + cb;
-        if (b >= B) break;
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < HP * WP; i += 64) {
-            const int r = i / WP - 1, c = i % WP - 1;
-            xs[i] = (r >= 0 && r < H && c >= 0 && c < W) ? x[(long)b * HW + r * W + c] : 0.f;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float *dzb = dz + (long)b * HW * 16;
-        int oh = 0, ow = lq;                 // this lane's pixel p = 4*step + lq
-        while (ow >= W) { ow -= W; ++oh; }
-        for (int p0 = 0; p0 < HW; p0 += 4) {
-            const int p = p0 + lq;
-            float a = 0.f, bv = 0.f;
-            if (p < HW) {
-                bv = dzb[p * 16 + li];
-                if (tap_ok) a = xs[(oh + kh) * WP + ow + kw];
-            }
-            acc = mfma16(a, bv, acc);
-            ow += 4;
-            while (ow >= W) { ow -= W; ++oh; }
-        }
-    }
-    // D[row = tap = 4*lq + r][col = co = li]; reduce the 4 waves through LDS
-    __syncthreads();
-    float *red = c1s;                        // [4][16][16]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * lq + r) * 16 + li] = acc[r];
-    __syncthreads();
-    if (threadIdx.x < 144) {
-        const int t = threadIdx.x / 16, c = threadIdx.x % 16;
-        atomicAdd(dw + threadIdx.x, red[(0 * 16 + t) * 16 + c] + red[(1 * 16 + t) * 16 + c] + red[(2 * 16 + t) * 16 + c] +
-                                        red[(3 * 16 + t) * 16 + c]);
-    }
 }
 
 // ---- per-channel sums over the rows of an (M x C) matrix, in double -------------------------------------------

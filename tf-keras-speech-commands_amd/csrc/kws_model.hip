@@ -85,8 +85,8 @@ inline void stat_grid(long M, int C, int &nblk, int &rows)
 template <int CR, int CO, int MODE, int EPI>
 void launch_gemm(const float *src, const float *w, const float *bias, float *dst, const ConvGeom &g, hipStream_t s)
 {
-    const long M = (long)g.B * (MODE == MODE_FWD ? g.Ho * g.Wo : g.H * g.W);
-    static const std::string name = std::string(MODE == MODE_FWD ? "conv_gemm_fwd<" : "conv_gemm_dgrad<") + std::to_string(CR) + "," +
+    const long M = (long)g.B * g.Ho * g.Wo;
+    static const std::string name = std::string("conv_gemm_fwd<") + std::to_string(CR) + "," +
                                     std::to_string(CO) + ">";
     KWS_LAUNCH(name.c_str(), (conv_gemm_kernel<CR, CO, MODE, EPI>), dim3(blocks_for(M, 64)), dim3(256), 0, s, src, w, bias, dst, g);
 }
@@ -164,8 +164,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         const float *kern = params + m->o_k[l];
         const long M = (long)B * Hz[l] * Wz[l];
         const int C = kCh[l + 1];
-        if (false) {
-        } else if (l == 1) {
+        if (l == 1) {
             launch_gemm<16, 32, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[1], geom3x3(B, Hs[1], Ws[1], 1), s);
         } else if (l == 2) {
             launch_gemm<32, 64, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s);

@@ -121,9 +121,10 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     import kws_amd
@@ -147,13 +148,13 @@ def main():
         step_no[0] += 1
         feat_fn(wav, out=feat)
         dm.train_fwd_bwd(feat, labels, dropout_seed=step_no[0], grad_scale=1.0 / world)
-        if world > 1:
+        if dist is not None:
             dist.all_reduce(dm.grads)      # RCCL sum over xGMI; 540 KB flat buffer
         dm.adam_step(1e-3)
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -164,19 +165,22 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(dm.stats[0].item()) / B
 
     # per-kernel timing on the launch stream (HIP events inside the library), separate from the timed region
+    # (every rank runs these steps -- they contain the all-reduce -- but only rank 0 records and reports)
     roofline, breakdown = None, {}
-    if rank == 0 and args.profile_steps > 0:
-        kws_amd.lib.prof_enable(True)
+    if args.profile_steps > 0:
+        if rank == 0:
+            kws_amd.lib.prof_enable(True)
         for _ in range(args.profile_steps):
             step()
-        torch.cuda.synchronize()
+        fence()
+    if rank == 0 and args.profile_steps > 0:
         rep = kws_amd.lib.prof_report()
         kws_amd.lib.prof_enable(False)
         models = kernel_models(B, N_CLASSES)
@@ -218,7 +222,8 @@ def main():
                           "train_step_hbm_roofline_frac": round(value / world * 229.8e3 / (HBM_PEAK_GBS * 1e9), 4)},
                "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown}
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

@@ -44,4 +44,21 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+// Full-wave (64-lane) sum entirely in the VALU: DPP row shifts inside each 16-lane row, then row_bcast15 / row_bcast31
+// across rows (the gfx9 wave64 reduction idiom).  No LDS crossbar round trips, unlike __shfl_xor (ds_bpermute).
+// The total is valid in lane 63; wave_sum_dpp() returns it broadcast to every lane.
+#define KWS_DPP_ADD(v, ctrl, row_mask) \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, row_mask, 0xf, false))
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    KWS_DPP_ADD(v, 0x111, 0xf);   // row_shr:1   (lanes shifted in from outside the row contribute the `old` value 0)
+    KWS_DPP_ADD(v, 0x112, 0xf);   // row_shr:2
+    KWS_DPP_ADD(v, 0x114, 0xf);   // row_shr:4
+    KWS_DPP_ADD(v, 0x118, 0xf);   // row_shr:8   -> lane 15 of every row holds its row sum
+    KWS_DPP_ADD(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    KWS_DPP_ADD(v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#undef KWS_DPP_ADD
+
 }  // namespace kws

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "kws_common.h"
+#include "kws_device.h"
 
 namespace kws {
 
@@ -207,7 +208,10 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
         dft8(v);
         wave_sync();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) s_fft[hi + 8 * lo + 64 * r] = v[r];
+        for (int r = 0; r < 8; ++r) {       // natural order k = hi + 8 lo + 64 r, stored at k + (k >> 3): the plain index
+            const int k = hi + 8 * lo + 64 * r;   // is a 4-way bank conflict (lo strides 16 words), the padded one 1-2 way
+            s_fft[k + (k >> 3)] = v[r];
+        }
         wave_sync();
 
         // real-FFT split: X[k] = E[k] + W_1024^k O[k], X[512-k] = conj(E[k] - W_1024^k O[k])
@@ -215,7 +219,8 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = lane + 64 * i;
-            const float2 zk = s_fft[k], zm = s_fft[(512 - k) & 511];
+            const int km = (512 - k) & 511;
+            const float2 zk = s_fft[k + (k >> 3)], zm = s_fft[km + (km >> 3)];
             const float2 E = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
             const float2 O = make_float2(0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
             const float2 T = cmul(c.tws[k], O);
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
             energy += pk[i] + pm[i];
         }
         if (lane == 0) {  // bin 256 is its own partner
-            const float2 z = s_fft[256];
+            const float2 z = s_fft[256 + 32];
             p256 = (z.x * z.x + z.y * z.y) * c.inv_nfft;
             energy += p256;
         }
@@ -237,8 +242,7 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
             s_pw[512 - k] = pm[i];
         }
         if (lane == 0) s_pw[256] = p256;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) energy += __shfl_xor(energy, o, 64);
+        energy = wave_sum_dpp(energy);      // VALU-only reduction (6 ds_bpermute round trips otherwise)
         wave_sync();
 
         // sparse band gather: lane = one chunk (<= chp bins) of one band's non-zero span.  Fixed trip count over

@@ -377,15 +377,32 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__r
         for (int mt = 0; mt < MW; ++mt) {
             // padding rows read the zero page: no op touches the loaded value before its MFMA, so the wait sits there
             const bool ok = live && (rmask[mt] & tapbit) == tapbit;
+#if defined(KWS_DGRAD_MODE) && KWS_DGRAD_MODE == 2      // diagnostic build: no global loads, MFMAs on constants
+            af[mt] = make_float4(ok ? 1.f : 0.f, 0.5f, 0.25f, 2.f);
+            continue;
+#endif
             af[mt] = *reinterpret_cast<const float4 *>(ok ? dz + (rbase[mt] - tapoff) : zeros + 4 * lq);
         }
         const float *wp = wgt + (tap * CO) * CR + 16 * n_jj + wrow;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const float4 *>(wp + 16 * nt * CR);
+        for (int nt = 0; nt < NT; ++nt) {
+#if defined(KWS_DGRAD_MODE) && KWS_DGRAD_MODE == 2
+            bf[nt] = make_float4(1.f, 2.f, 3.f, (float)tap);
+            continue;
+#endif
+            bf[nt] = *reinterpret_cast<const float4 *>(wp + 16 * nt * CR);
+        }
         if (++n_jj == JJ) { n_jj = 0; if (++n_tw == nkw) { n_tw = 0; ++n_th; } }
     };
 
     auto mma = [&](const float4 (&af)[MW], const float4 (&bf)[NT]) {
+#if defined(KWS_DGRAD_MODE) && KWS_DGRAD_MODE == 1      // diagnostic build (tools/dgrad_modes.hip): keep the loads, drop the MFMAs
+#pragma unroll
+        for (int mt = 0; mt < MW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt][0] += af[mt].x + bf[nt].y;
+        return;
+#endif
         // k-step outermost: consecutive MFMAs hit different accumulators
 #pragma unroll
         for (int mt = 0; mt < MW; ++mt)
@@ -448,6 +465,189 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__r
                 for (int nt = 0; nt < NT; ++nt) o[16 * nt] = acc[mt][nt][r];
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Clip-resident kernels for a 3x3 / stride-1 / 'same' layer with FEW channels (conv2: 16 -> 32).
+// Measured on the LDS-free kernels above: loads alone cost as much as loads + MFMAs (every dz row is fetched once per
+// tap through the texture path, every wave re-fetches the weights).  Here a block walks whole clips: the clip's tile is
+// staged in LDS ONCE (zero halo = padding), fragments are LDS reads at tap offsets, and the wave's weight fragments
+// (dgrad) or accumulators (wgrad) live in registers for the whole kernel.
+// ---------------------------------------------------------------------------------------------------------------
+// dx[b][ih][iw][n] = sum_{tap,c} dz[b][ih+1-kh][iw+1-kw][c] * W[tap][n][c],  CR = c range (conv Cout), CO = 16 (conv Cin)
+template <int CR>
+__global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(const float *__restrict__ dz, const float *__restrict__ wgt,
+                                                               float *__restrict__ dx, int B, int H, int W)
+{
+    constexpr int CO = 16, JJ = CR / 16, CRP = CR + 4;           // padded pixel stride: spreads ds_read_b128 over the banks
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [(H+2)][(W+2)][CRP], zero halo
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const int HP = H + 2, WP = W + 2, HW = H * W, ntile = (HW + 15) / 16;
+    for (int i = threadIdx.x; i < HP * WP * CRP; i += 256) tile[i] = 0.f;
+
+    // this wave's weight fragments for every (tap, jj): lane holds W[tap][n = li][c = 16 jj + 4 lq .. +3]
+    float4 wf[9][JJ];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int jj = 0; jj < JJ; ++jj) wf[t][jj] = *reinterpret_cast<const float4 *>(wgt + ((t * CO + li) * CR + 16 * jj + 4 * lq));
+
+    constexpr int F4 = CR / 4;                                    // float4 per pixel
+    constexpr int PF = 8;                                         // float4 held per thread for the next clip (<= 2048 per clip)
+    const int nf4 = HW * F4;
+    float4 pf[PF];
+    auto prefetch = [&](int b) {
+        const float4 *src = reinterpret_cast<const float4 *>(dz + (long)b * HW * CR);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            pf[j] = i < nf4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if ((int)blockIdx.x < B) prefetch(blockIdx.x);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();                                          // previous clip's reads are done
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nf4) {
+                const int pix = i / F4, c4 = i % F4, y = pix / W, x = pix % W;
+                *reinterpret_cast<float4 *>(&tile[((y + 1) * WP + x + 1) * CRP + 4 * c4]) = pf[j];
+            }
+        }
+        if (nf4 > 256 * PF) {                                     // larger clips: the remainder goes straight through
+            const float4 *src = reinterpret_cast<const float4 *>(dz + (long)b * HW * CR);
+            for (int i = threadIdx.x + 256 * PF; i < nf4; i += 256) {
+                const int pix = i / F4, c4 = i % F4, y = pix / W, x = pix % W;
+                *reinterpret_cast<float4 *>(&tile[((y + 1) * WP + x + 1) * CRP + 4 * c4]) = src[i];
+            }
+        }
+        __syncthreads();
+        if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);      // next clip's HBM latency hides under this clip's MFMAs
+        for (int t = wave; t < ntile; t += 4) {
+            const int p = 16 * t + li, pc = p < HW ? p : HW - 1;  // A-fragment row (clamped: extra rows are not stored)
+            const int ih = pc / W, iw = pc % W;
+            // source pixel of tap (kh, kw) in tile coordinates: (ih + 1 - kh + 1, iw + 1 - kw + 1)
+            const float *a0 = &tile[((ih + 2) * WP + iw + 2) * CRP + 4 * lq];
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                    for (int jj = 0; jj < JJ; ++jj) {
+                        const float4 a = *reinterpret_cast<const float4 *>(a0 - (kh * WP + kw) * CRP + 16 * jj);
+                        const float4 w = wf[kh * 3 + kw][jj];
+                        acc = mfma16(a.x, w.x, acc);
+                        acc = mfma16(a.y, w.y, acc);
+                        acc = mfma16(a.z, w.z, acc);
+                        acc = mfma16(a.w, w.w, acc);
+                    }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int po = 16 * t + 4 * lq + r;
+                if (po < HW) dx[((long)b * HW + po) * CO + li] = acc[r];
+            }
+        }
+    }
+}
+
+// dW[tap][ci][co] += sum_pixels x[b][oh+kh-1][ow+kw-1][ci] * dz[b][oh][ow][co],  CIN = 16, COUT = 32, all 9 taps per wave
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_wgrad_clip_kernel(const float *__restrict__ x, const float *__restrict__ dz,
+                                                               float *__restrict__ dw, int B, int H, int W)
+{
+    constexpr int CIN = 16, NT = COUT / 16, XS = 16, DS = stride16(COUT);   // LDS row strides (== 16 mod 32 words)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const int HP = H + 2, WP = W + 2, HW = H * W, nstep = (HW + 3) / 4;
+    float *xt = smem;                                             // [(H+2)][(W+2)][16], zero halo
+    float *dt = smem + HP * WP * XS;                              // [4*nstep][DS], rows >= HW are zero
+    for (int i = threadIdx.x; i < HP * WP * XS + 4 * nstep * DS; i += 256) smem[i] = 0.f;
+
+    f32x4 acc[9][NT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int PX = 3, PD = 5;                                 // float4 per thread: x (<= 768 per clip), dz (<= 1280)
+    const int nx4 = HW * (CIN / 4), nd4 = HW * (COUT / 4);
+    float4 px[PX], pd[PD];
+    auto prefetch = [&](int b) {
+        const float4 *xs = reinterpret_cast<const float4 *>(x + (long)b * HW * CIN);
+        const float4 *ds = reinterpret_cast<const float4 *>(dz + (long)b * HW * COUT);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) { const int i = threadIdx.x + 256 * j; px[j] = i < nx4 ? xs[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int j = 0; j < PD; ++j) { const int i = threadIdx.x + 256 * j; pd[j] = i < nd4 ? ds[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    };
+    if ((int)blockIdx.x < B) prefetch(blockIdx.x);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nx4) {
+                const int pix = i / (CIN / 4), c4 = i % (CIN / 4), y = pix / W, xx = pix % W;
+                *reinterpret_cast<float4 *>(&xt[((y + 1) * WP + xx + 1) * XS + 4 * c4]) = px[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nd4) *reinterpret_cast<float4 *>(&dt[(i / (COUT / 4)) * DS + 4 * (i % (COUT / 4))]) = pd[j];
+        }
+        if (nx4 > 256 * PX || nd4 > 256 * PD) {                   // larger clips: the remainder goes straight through
+            const float4 *xs = reinterpret_cast<const float4 *>(x + (long)b * HW * CIN);
+            for (int i = threadIdx.x + 256 * PX; i < nx4; i += 256) {
+                const int pix = i / (CIN / 4), c4 = i % (CIN / 4), y = pix / W, xx = pix % W;
+                *reinterpret_cast<float4 *>(&xt[((y + 1) * WP + xx + 1) * XS + 4 * c4]) = xs[i];
+            }
+            const float4 *ds = reinterpret_cast<const float4 *>(dz + (long)b * HW * COUT);
+            for (int i = threadIdx.x + 256 * PD; i < nd4; i += 256)
+                *reinterpret_cast<float4 *>(&dt[(i / (COUT / 4)) * DS + 4 * (i % (COUT / 4))]) = ds[i];
+        }
+        __syncthreads();
+        if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
+        for (int st = wave; st < nstep; st += 4) {
+            const int p = 4 * st + lq, pc = p < HW ? p : HW - 1;  // rows >= HW multiply dt rows that are zero
+            const int oh = pc / W, ow = pc % W;
+            float bf[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = dt[p * DS + 16 * nt + li];
+            const float *a0 = &xt[(oh * WP + ow) * XS + li];      // tap (0,0) of this pixel in halo coordinates
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float a = a0[(kh * WP + kw) * XS];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[kh * 3 + kw][nt] = mfma16(a, bf[nt], acc[kh * 3 + kw][nt]);
+                }
+        }
+    }
+    // reduce the 4 waves through LDS (reusing the tile space) and add to global memory with contiguous atomics
+    float *red = smem;                                            // [4][64][4] then [16][COUT] rows
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            __syncthreads();
+            *reinterpret_cast<f32x4 *>(&red[(wave * 64 + lane) * 4]) = acc[t][nt];
+            __syncthreads();
+            if (wave == 0) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(&red[(0 * 64 + lane) * 4]);
+                const f32x4 s1 = *reinterpret_cast<const f32x4 *>(&red[(1 * 64 + lane) * 4]);
+                const f32x4 s2 = *reinterpret_cast<const f32x4 *>(&red[(2 * 64 + lane) * 4]);
+                const f32x4 s3 = *reinterpret_cast<const f32x4 *>(&red[(3 * 64 + lane) * 4]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[1024 + (4 * lq + r) * COUT + 16 * nt + li] = (s0[r] + s1[r]) + (s2[r] + s3[r]);
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 16 * COUT; idx += 256) atomicAdd(dw + (long)t * CIN * COUT + idx, red[1024 + idx]);
+    }
 }
 
 }  // namespace kws

@@ -281,9 +281,14 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2);
             launch_dgrad<64, 32, 4, 2>(w.gz[2], kern, w.da[1], g, s);
         } else {
-            const ConvGeom g = geom3x3(B, Hs[1], Ws[1], 1);
-            launch_wgrad<16, 32, 9>(in, w.gz[1], dk, g, s2);
-            launch_dgrad<32, 16, 4, 1>(w.gz[1], kern, w.da[0], g, s);
+            // conv2 (16 -> 32, 3x3, stride 1): clip-resident kernels, the clip's tiles are staged in LDS once
+            const int H1 = Hs[1], W1 = Ws[1];
+            const unsigned nblk = (unsigned)std::min(B, 256 * 3), nblk_d = (unsigned)std::min(B, 256 * 5);   // LDS-limited residency
+            const size_t smw = sizeof(float) * ((size_t)(H1 + 2) * (W1 + 2) * 16 + (size_t)((H1 * W1 + 3) / 4) * 4 * stride16(32));
+            const size_t smw2 = std::max(smw, sizeof(float) * (size_t)(1024 + 16 * 32));
+            KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);
+            const size_t smd = sizeof(float) * (size_t)(H1 + 2) * (W1 + 2) * (32 + 4);
+            KWS_LAUNCH("conv_dgrad_clip<32,16>", conv_dgrad_clip_kernel<32>, dim3(nblk_d), dim3(256), smd, s, w.gz[1], kern, w.da[0], B, H1, W1);
         }
     }
     // layer 1: da1 -> (dgamma1, dbeta1, dW1) with conv1 recomputed; no z1-sized tensor is read or written

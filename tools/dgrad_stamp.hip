@@ -4,7 +4,11 @@
 #include <cstdio>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef NO_STAMPS
+#define STAMP(var) do { var = 0; } while (0)
+#else
 #define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 
 template <int MODE>   // 0: normal, 1: no MFMA (loads only), 2: no loads (MFMA only on stale regs)
 __global__ __launch_bounds__(256) void k(const float *__restrict__ dz, const float *__restrict__ wgt, float *__restrict__ dx, int B,

@@ -194,6 +194,9 @@ int kws_loss_forward(const float *y_pred, const int32_t *labels, const float *cl
 int kws_adam_step(float *params, const float *grads, float *m, float *v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int64_t t, float grad_scale, void *stream);
 
+/* Evaluation (eval.py:201-256): counts[label * C + pred] += 1 for every sample of the batch (int32, caller zeroes it). */
+int kws_confusion_counts(const int32_t *labels, const int32_t *pred, int B, int C, int32_t *counts, void *stream);
+
 /* keras SGD(momentum=0) and RMSprop(rho=0.9, momentum=0, epsilon=1e-7, centered=False), model_utils.py:48-51:
  *   sgd:     p -= lr * g
  *   rmsprop: a = rho a + (1-rho) g^2;  p -= lr * g / (sqrt(a) + eps)            with g = grad_scale * grads */

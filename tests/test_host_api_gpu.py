@@ -152,3 +152,21 @@ def test_get_dataset_builds_reference_compatible_cache(torch, golden, tmp_path):
     assert len(x2) == 6 and sorted(y2.tolist()) == [0, 0, 1, 1, 2, 2]
     full = x2[[i for i in range(6) if y2[i] == 1]]
     assert min(np.abs(f[..., 0] - golden["refpy_mel_right_1"]).max() for f in full) < 2e-4
+
+
+def test_eval_harness_confusion_matrix(torch):
+    import eval as kws_eval
+    from classifier.model import get_model
+    from oracle import model_oracle as mo
+    C = 6
+    names = ["background"] + ["w%d" % i for i in range(1, C)]
+    x, y = separable(700, C, 9)
+    m = get_model("simple_cnn", C)
+    acc, cm = kws_eval.evaluate_accuracy(m, x, y, names, batch_size=256)
+    om = mo.Model("simple_cnn", C)
+    om.set_weights(m.get_weights())
+    want = om.predict(x[..., 0].astype(np.float64)).argmax(-1)
+    ref = np.zeros((C, C), np.int64)
+    np.add.at(ref, (y, want), 1)
+    assert cm.sum() == 700 and abs(acc - (want == y).mean()) < 0.01
+    assert np.abs(cm - ref).sum() <= 4          # an untrained net has near-tied scores on a few clips

@@ -388,6 +388,16 @@ __global__ __launch_bounds__(256) void loss_forward_kernel(const float *__restri
     losses[b] = loss;
 }
 
+// counts[label][pred] += 1 over a batch (eval.py:201-256 builds the same matrix with sklearn on the host)
+__global__ __launch_bounds__(256) void confusion_kernel(const int32_t *__restrict__ labels, const int32_t *__restrict__ pred, int B,
+                                                         int C, int32_t *__restrict__ counts)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int y = labels[b], p = pred[b];
+    if (y >= 0 && y < C && p >= 0 && p < C) atomicAdd(counts + y * C + p, 1);
+}
+
 __global__ __launch_bounds__(256) void sgd_kernel(float *__restrict__ p, const float *__restrict__ g, long n, float lr, float gs)
 {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;

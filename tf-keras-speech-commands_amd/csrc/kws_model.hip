@@ -652,6 +652,16 @@ int kws_adam_step(float *params, const float *grads, float *m, float *v, int64_t
     return KWS_OK;
 }
 
+int kws_confusion_counts(const int32_t *labels, const int32_t *pred, int B, int C, int32_t *counts, void *stream)
+{
+    if (!labels || !pred || !counts || B < 0 || C < 1) return fail(KWS_ERR_INVALID, "bad argument");
+    if (B == 0) return KWS_OK;
+    KWS_LAUNCH("confusion_kernel", confusion_kernel, dim3(blocks_for(B, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), labels, pred, B,
+               C, counts);
+    KWS_LAUNCH_CHECK("confusion_kernel");
+    return KWS_OK;
+}
+
 int kws_sgd_step(float *params, const float *grads, int64_t n, float lr, float grad_scale, void *stream)
 {
     if (!params || !grads || n < 0) return fail(KWS_ERR_INVALID, "bad argument");

@@ -84,6 +84,7 @@ def get_lib():
     L.kws_model_grad_split.argtypes = [vp]
     L.kws_model_grad_split.restype = i64
     L.kws_loss_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    L.kws_confusion_counts.argtypes = [vp, vp, i32, i32, vp, vp]
     L.kws_sgd_step.argtypes = [vp, vp, i64, f32, f32, vp]
     L.kws_rmsprop_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, vp]
     L.kws_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp]

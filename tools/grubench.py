@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tf-keras-speech-commands_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tf-keras-speech-commands_amd"))
 import torch, kws_amd
 from kws_amd.model import DeviceModel, ModelSpec
 from kws_amd.init import init_weights

@@ -191,3 +191,30 @@ def test_full_size_properties_b4096(torch, feat):
     fo = _oracle()
     for b in idx:
         np.testing.assert_allclose(out[b].cpu().numpy(), fo.audio_to_feature(wav[b].double().cpu().numpy()), atol=ATOL)
+
+
+def test_other_fft_sizes_generic_kernel(torch):
+    """n_fft != 1024 runs the generic radix-2 kernel: cropped window (window > n_fft), exact fit, zero padding, deltas,
+    bark bank, int16 input and ragged lengths."""
+    from classifier.params import ListenerParams
+    from kws_amd.featurizer import Featurizer
+    fo = _oracle()
+    rng = np.random.default_rng(12)
+    lens = np.array([16000, 5000, 0, 16000], np.int32)
+    a = np.round(np.clip(0.1 * rng.standard_normal((4, 16000)), -1, 1) * 32768) / 32768
+    cases = [dict(n_fft=512, window_t=0.032, hop_t=0.016, n_filt=20, n_mfcc=13),       # window == n_fft
+             dict(n_fft=2048, window_t=0.064, hop_t=0.032, n_filt=20, n_mfcc=20),      # zero padded to 2048
+             dict(n_fft=512, window_t=0.064, hop_t=0.032, n_filt=20, n_mfcc=20),       # window 1024 cropped to 512
+             dict(n_fft=256, window_t=0.016, hop_t=0.008, n_filt=13, n_mfcc=13, use_delta=True)]
+    for kw in cases:
+        p = ListenerParams(1.0, kw["window_t"], kw["hop_t"], 16000, 2, kw["n_fft"], kw["n_filt"], kw["n_mfcc"],
+                           kw.get("use_delta", False), ((6, 4),), 0.2)
+        for bank in ("mel", "bark") if kw["n_fft"] >= 512 else ("mel",):
+            f = Featurizer(p, bank)
+            got = f(torch.from_numpy(a.astype(np.float32)).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy()
+            for b in range(4):
+                want = fo.audio_to_feature(a[b, :lens[b]], kind=bank, **kw)
+                np.testing.assert_allclose(got[b], want, atol=ATOL if not kw.get("use_delta") else 2 * ATOL, rtol=0,
+                                           err_msg="%s %s clip %d" % (kw, bank, b))
+        got16 = Featurizer(p)(torch.from_numpy((a * 32768).astype(np.int16)).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy()
+        np.testing.assert_allclose(got16, Featurizer(p)(torch.from_numpy(a.astype(np.float32)).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy(), atol=1e-6)

@@ -40,6 +40,12 @@ struct FeatDev {
     const int *bcs;      // [n_filt+1] first chunk of each band
     const float *w;      // [nchunks][chp] bank weights, zero padded (nnz = nchunks*chp)
     const float *dct;    // [n_filt_pad][n_out], ortho scaling folded in, zero rows past n_filt
+    // generic path (n_fft != 1024): radix-2 twiddles and the bank as per-band spans
+    int n_fft, log2n;
+    const float2 *twg;   // [n_fft/2]  W_nfft^k
+    const int *bfirst;   // [n_filt] first non-zero bin of each band
+    const int *bwidth;   // [n_filt] span length
+    const float *bw;     // [n_filt][n_bins] dense bank rows (float)
 };
 
 }  // namespace kws
@@ -307,6 +313,94 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Generic fallback for n_fft != 1024 (any power of two 64..4096): same block = clip / wave = frames mapping, but a plain
+// in-LDS radix-2 FFT of the zero-padded real frame and per-band loops.  Correct for every params.json the reference
+// accepts; the tuned kernel above is the one the default geometry (and the benchmark) uses.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kGenWaves = 4;
+
+template <typename WavT>
+__global__ __launch_bounds__(kGenWaves * 64) void featurize_generic_kernel(const WavT *__restrict__ wav, int64_t stride,
+                                                                           const int32_t *__restrict__ valid_len, int B, FeatDev c,
+                                                                           float *__restrict__ feat)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+    if (b >= B) return;
+    const int N = c.n_fft, nb = N / 2 + 1;
+    float2 *z = reinterpret_cast<float2 *>(smem) + (size_t)wave * N;                       // [N] complex per wave
+    float *s_mel = reinterpret_cast<float *>(smem + (size_t)kGenWaves * N * 8) + wave * 64;
+    float *s_feat = reinterpret_cast<float *>(smem + (size_t)kGenWaves * N * 8 + kGenWaves * 256);
+
+    int len = valid_len ? valid_len[b] : (stride > c.max_samples ? c.max_samples : (int)stride);
+    len = len < 0 ? 0 : len;
+    if ((int64_t)len > stride) len = (int)stride;
+    if (len > c.max_samples) len = c.max_samples;
+    const int pad = c.max_samples - len;
+    const WavT *src = wav + (int64_t)b * stride;
+
+    for (int f = wave; f < c.n_frames; f += kGenWaves) {
+        const int base = f * c.hop;
+        for (int i = lane; i < N; i += 64) {                       // bit-reversed load of the (cropped / zero-padded) frame
+            const int p = base + i;
+            const float v = (i < c.window_eff && p >= pad) ? to_f32(src[p - pad]) : 0.f;
+            z[__brev((unsigned)i) >> (32 - c.log2n)] = make_float2(v, 0.f);
+        }
+        wave_sync();
+        for (int st = 1; st <= c.log2n; ++st) {                    // radix-2 decimation in time
+            const int half = 1 << (st - 1), tstep = N >> st;
+            for (int i = lane; i < N / 2; i += 64) {
+                const int k = i & (half - 1), j = ((i >> (st - 1)) << st) + k;
+                const float2 w = c.twg[k * tstep], u = z[j], t = cmul(w, z[j + half]);
+                z[j] = cadd(u, t);
+                z[j + half] = csub(u, t);
+            }
+            wave_sync();
+        }
+        float e = 0.f;
+        float *pw = reinterpret_cast<float *>(z);                  // power spectrum overwrites the low half in place
+        for (int k0 = 0; k0 < nb; k0 += 64) {
+            const int k = k0 + lane;
+            float pk = 0.f;
+            if (k < nb) { const float2 x = z[k]; pk = (x.x * x.x + x.y * x.y) * c.inv_nfft; }
+            wave_sync();                                           // every lane has read its z[k] of this group
+            if (k < nb) pw[k] = pk;
+            e += pk;
+        }
+        e = wave_sum(e);
+        wave_sync();
+        float melv = 0.f;
+        if (lane < c.n_filt) {
+            const float *w = c.bw + (size_t)lane * nb + c.bfirst[lane];
+            const float *pp = pw + c.bfirst[lane];
+            float sacc = 0.f;
+            for (int t = 0; t < c.bwidth[lane]; ++t) sacc = fmaf(pp[t], w[t], sacc);
+            melv = logf(fmaxf(sacc, kEps));
+        }
+        s_mel[lane] = melv;
+        wave_sync();
+        if (lane < c.n_out) {
+            float sacc = 0.f;
+            for (int n = 0; n < c.n_filt; ++n) sacc = fmaf(s_mel[n], c.dct[n * c.n_out + lane], sacc);
+            if (lane == 0) sacc = logf(fmaxf(e, kEps));
+            s_feat[f * c.n_out + lane] = sacc;
+        }
+        wave_sync();
+    }
+    __syncthreads();
+    float *dst = feat + (int64_t)b * c.n_frames * c.feature_size;
+    const int total = c.n_frames * c.feature_size;
+    for (int i = tid; i < total; i += kGenWaves * 64) {
+        const int fr = i / c.feature_size, col = i - fr * c.feature_size;
+        float val;
+        if (col < c.n_out) val = s_feat[fr * c.n_out + col];
+        else val = fr == 0 ? 0.f : s_feat[fr * c.n_out + col - c.n_out] - s_feat[(fr - 1) * c.n_out + col - c.n_out];
+        dst[i] = val;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side: parameter geometry and table construction (double precision, then rounded once)
 // ---------------------------------------------------------------------------------------------
@@ -409,7 +503,8 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     if (p->n_filt < 1 || p->n_filt > 64) return fail(KWS_ERR_UNSUPPORTED, "n_filt must be in 1..64, got %d", p->n_filt);
     if (p->n_mfcc < 1 || p->n_mfcc > p->n_filt)
         return fail(KWS_ERR_INVALID, "n_mfcc=%d must be in 1..n_filt=%d (the reference's feature_size would not match)", p->n_mfcc, p->n_filt);
-    if (p->n_fft != 1024) return fail(KWS_ERR_UNSUPPORTED, "only n_fft=1024 has a HIP kernel so far (got %d)", p->n_fft);
+    if (p->n_fft < 64 || p->n_fft > 4096 || (p->n_fft & (p->n_fft - 1)))
+        return fail(KWS_ERR_UNSUPPORTED, "n_fft must be a power of two in 64..4096 (got %d)", p->n_fft);
     if (g.max_samples < g.window_samples) return fail(KWS_ERR_INVALID, "buffer shorter than one window");
     const int n_frames = (g.max_samples - g.window_samples) / g.hop_samples + 1;
     if (n_frames != g.n_features)
@@ -464,6 +559,14 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
         const double a = -2.0 * M_PI * (double)k / 1024.0;
         tws[k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
+    // generic-path tables (used when n_fft != 1024)
+    std::vector<float2> twg((size_t)p->n_fft / 2);
+    for (int k = 0; k < p->n_fft / 2; ++k) {
+        const double a = -2.0 * M_PI * (double)k / (double)p->n_fft;
+        twg[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    std::vector<float> bwf(bank.size());
+    for (size_t i = 0; i < bank.size(); ++i) bwf[i] = (float)bank[i];
     std::vector<float> dct((size_t)n_filt_pad * n_out, 0.f);
     for (int n = 0; n < n_filt; ++n)
         for (int k = 0; k < n_out; ++k)  // scipy dct type II norm='ortho' (bark_feature.py:172, mfcc.h:55-67)
@@ -484,7 +587,8 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     const size_t o_tw1 = 0, o_tw2 = al(o_tw1 + tw1.size() * 8), o_tws = al(o_tw2 + tw2.size() * 8),
                  o_ch = al(o_tws + tws.size() * 8), o_bcs = al(o_ch + std::max<size_t>(1, chunks.size()) * 16),
                  o_w = al(o_bcs + bcs.size() * 4), o_dct = al(o_w + std::max<size_t>(1, w.size()) * 4),
-                 total = al(o_dct + dct.size() * 4);
+                 o_twg = al(o_dct + dct.size() * 4), o_bf = al(o_twg + twg.size() * 8), o_bwd = al(o_bf + first.size() * 4),
+                 o_bw = al(o_bwd + width.size() * 4), total = al(o_bw + bwf.size() * 4);
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + o_tw1, tw1.data(), tw1.size() * 8);
     std::memcpy(host.data() + o_tw2, tw2.data(), tw2.size() * 8);
@@ -493,6 +597,10 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     std::memcpy(host.data() + o_bcs, bcs.data(), bcs.size() * 4);
     if (!w.empty()) std::memcpy(host.data() + o_w, w.data(), w.size() * 4);
     std::memcpy(host.data() + o_dct, dct.data(), dct.size() * 4);
+    std::memcpy(host.data() + o_twg, twg.data(), twg.size() * 8);
+    std::memcpy(host.data() + o_bf, first.data(), first.size() * 4);
+    std::memcpy(host.data() + o_bwd, width.data(), width.size() * 4);
+    std::memcpy(host.data() + o_bw, bwf.data(), bwf.size() * 4);
     hipError_t e = hipMalloc(&f->dmem, total);
     if (e == hipSuccess) e = hipMemcpy(f->dmem, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -514,6 +622,13 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     d.bcs = reinterpret_cast<const int *>(base + o_bcs);
     d.w = reinterpret_cast<const float *>(base + o_w);
     d.dct = reinterpret_cast<const float *>(base + o_dct);
+    d.n_fft = p->n_fft;
+    d.log2n = 0;
+    while ((1 << d.log2n) < p->n_fft) ++d.log2n;
+    d.twg = reinterpret_cast<const float2 *>(base + o_twg);
+    d.bfirst = reinterpret_cast<const int *>(base + o_bf);
+    d.bwidth = reinterpret_cast<const int *>(base + o_bwd);
+    d.bw = reinterpret_cast<const float *>(base + o_bw);
     f->smem_bytes = (size_t)kWaves * (kFftTile * 8 + 512) + 1024 + 272 +
                     4 * (size_t)(round4(n_filt_pad * n_out) + round4(d.nnz) + round4(n_frames * n_out)) + 8 * (7 * 64 + 7 * 8);
     if (f->smem_bytes > 64 * 1024) {
@@ -553,9 +668,36 @@ static size_t feat_smem_bytes(const FeatDev &d)
            4 * (size_t)(round4(d.n_filt_pad * d.n_out) + round4(d.nnz) + round4(d.n_frames * d.n_out)) + 8 * (7 * 64 + 7 * 8);
 }
 
+static int launch_generic(const FeatDev &d, const void *wav, int wav_dtype, int B, int64_t stride, const int32_t *valid_len,
+                          float *feat, void *stream)
+{
+    const size_t smem = (size_t)kGenWaves * d.n_fft * 8 + kGenWaves * 256 + 4 * (size_t)round4(d.n_frames * d.n_out);
+    if (smem > 160 * 1024) return fail(KWS_ERR_UNSUPPORTED, "n_fft=%d with %d frames needs %zu B of LDS (> 160 KiB)", d.n_fft, d.n_frames, smem);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)B), block(kGenWaves * 64);
+    if (wav_dtype == KWS_WAV_F32) {
+        if (smem > 64 * 1024)
+            KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_generic_kernel<float>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        KWS_LAUNCH("featurize_generic_f32", featurize_generic_kernel<float>, grid, block, smem, s, static_cast<const float *>(wav), stride,
+                   valid_len, B, d, feat);
+    } else if (wav_dtype == KWS_WAV_I16) {
+        if (smem > 64 * 1024)
+            KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_generic_kernel<short>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        KWS_LAUNCH("featurize_generic_i16", featurize_generic_kernel<short>, grid, block, smem, s, static_cast<const short *>(wav), stride,
+                   valid_len, B, d, feat);
+    } else {
+        return fail(KWS_ERR_INVALID, "unknown wav dtype %d", wav_dtype);
+    }
+    KWS_LAUNCH_CHECK("featurize_generic_kernel");
+    return KWS_OK;
+}
+
 static int launch_featurize(const FeatDev &d, const void *wav, int wav_dtype, int B, int64_t stride,
                             const int32_t *valid_len, float *feat, void *stream)
 {
+    if (d.n_fft != 1024) return launch_generic(d, wav, wav_dtype, B, stride, valid_len, feat, stream);
     const size_t smem = feat_smem_bytes(d);
     if (smem > 160 * 1024) return fail(KWS_ERR_UNSUPPORTED, "%d frames need %zu B of LDS (> 160 KiB)", d.n_frames, smem);
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -474,6 +474,120 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__r
 // staged in LDS ONCE (zero halo = padding), fragments are LDS reads at tap offsets, and the wave's weight fragments
 // (dgrad) or accumulators (wgrad) live in registers for the whole kernel.
 // ---------------------------------------------------------------------------------------------------------------
+// z[b][oh][ow][n] = sum_{tap,c} x[b][oh+kh-1][ow+kw-1][c] * W[tap][c][n],  CIN = 16, COUT = 16*NT (conv2 forward).
+// K order permuted (k = 4 lq + j inside a tap) so the A fragment is ONE ds_read_b128 per tap; the wave's 9 x 4 x NT weight
+// fragments stay in registers.  The BatchNormalization batch statistics are fused: every lane accumulates sum / sum of
+// squares of its output column and the block writes ONE double partial per channel (the layout bn_finalize_train_kernel
+// reads), so the pre-BN tensor is not re-read by a statistics pass.
+template <int COUT, bool STATS>
+__global__ __launch_bounds__(256) void conv_fwd_clip_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
+                                                             float *__restrict__ z, int B, int H, int W,
+                                                             double *__restrict__ partial, int partial_stride)
+{
+    constexpr int CIN = 16, NT = COUT / 16, XP = CIN + 4;          // padded pixel stride (words)
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [(H+2)][(W+2)][XP], zero halo
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const int HP = H + 2, WP = W + 2, HW = H * W, ntile = (HW + 15) / 16;
+    for (int i = threadIdx.x; i < HP * WP * XP; i += 256) tile[i] = 0.f;
+
+    // B fragments: k-step j of tap t multiplies input channel 4 lq + j; lane holds W[t][4 lq + j][16 nt + li]
+    float wf[9][4][NT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[t][j][nt] = wgt[(t * CIN + 4 * lq + j) * COUT + 16 * nt + li];
+
+    constexpr int PF = 3;                                         // float4 per thread for the next clip (<= 768 per clip)
+    const int nf4 = HW * (CIN / 4);
+    float4 pf[PF];
+    auto prefetch = [&](int b) {
+        const float4 *src = reinterpret_cast<const float4 *>(x + (long)b * HW * CIN);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) { const int i = threadIdx.x + 256 * j; pf[j] = i < nf4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    };
+    float ssum[NT], ssq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.f; ssq[nt] = 0.f; }
+
+    if ((int)blockIdx.x < B) prefetch(blockIdx.x);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nf4) {
+                const int pix = i / (CIN / 4), c4 = i % (CIN / 4), y = pix / W, xx = pix % W;
+                *reinterpret_cast<float4 *>(&tile[((y + 1) * WP + xx + 1) * XP + 4 * c4]) = pf[j];
+            }
+        }
+        if (nf4 > 256 * PF) {
+            const float4 *src = reinterpret_cast<const float4 *>(x + (long)b * HW * CIN);
+            for (int i = threadIdx.x + 256 * PF; i < nf4; i += 256) {
+                const int pix = i / (CIN / 4), c4 = i % (CIN / 4), y = pix / W, xx = pix % W;
+                *reinterpret_cast<float4 *>(&tile[((y + 1) * WP + xx + 1) * XP + 4 * c4]) = src[i];
+            }
+        }
+        __syncthreads();
+        if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
+        for (int t = wave; t < ntile; t += 4) {
+            const int p = 16 * t + li, pc = p < HW ? p : HW - 1;
+            const int oh = pc / W, ow = pc % W;
+            const float *a0 = &tile[(oh * WP + ow) * XP + 4 * lq];  // tap (0,0) of this pixel in halo coordinates
+            f32x4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float4 a = *reinterpret_cast<const float4 *>(a0 + (kh * WP + kw) * XP);
+                    const int tp = kh * 3 + kw;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a.x, wf[tp][0][nt], acc[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a.y, wf[tp][1][nt], acc[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a.z, wf[tp][2][nt], acc[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a.w, wf[tp][3][nt], acc[nt]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int po = 16 * t + 4 * lq + r;
+                if (po < HW) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float v = acc[nt][r];
+                        z[((long)b * HW + po) * COUT + 16 * nt + li] = v;
+                        if (STATS) { ssum[nt] += v; ssq[nt] = fmaf(v, v, ssq[nt]); }
+                    }
+                }
+            }
+        }
+    }
+    if (STATS) {
+        // lanes with equal li hold the same column: reduce over lq (xor 16, 32), then over the 4 waves through LDS
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(tile);          // [4 waves][2][COUT]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            double a = (double)ssum[nt], q = (double)ssq[nt];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            if (lq == 0) { red[(wave * 2 + 0) * COUT + 16 * nt + li] = a; red[(wave * 2 + 1) * COUT + 16 * nt + li] = q; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * COUT) {
+            const int which = threadIdx.x / COUT, c = threadIdx.x % COUT;
+            const double v = (red[(0 * 2 + which) * COUT + c] + red[(1 * 2 + which) * COUT + c]) +
+                             (red[(2 * 2 + which) * COUT + c] + red[(3 * 2 + which) * COUT + c]);
+            partial[((long)which * COUT + c) * partial_stride + blockIdx.x] = v;
+        }
+    }
+}
+
 // dx[b][ih][iw][n] = sum_{tap,c} dz[b][ih+1-kh][iw+1-kw][c] * W[tap][n][c],  CR = c range (conv Cout), CO = 16 (conv Cin)
 template <int CR>
 __global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(const float *__restrict__ dz, const float *__restrict__ wgt,

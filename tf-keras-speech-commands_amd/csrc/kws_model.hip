@@ -164,8 +164,19 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         const float *kern = params + m->o_k[l];
         const long M = (long)B * Hz[l] * Wz[l];
         const int C = kCh[l + 1];
+        int fused_stat_blocks = 0;           // > 0: the conv kernel already wrote the BN partial sums
         if (l == 1) {
-            launch_gemm<16, 32, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[1], geom3x3(B, Hs[1], Ws[1], 1), s);
+            // conv2: clip-resident kernel, batch statistics fused into the epilogue when training
+            const unsigned nblk = (unsigned)std::min(B, kMaxStatBlocks);
+            const size_t sm = std::max(sizeof(float) * (size_t)(Hs[1] + 2) * (Ws[1] + 2) * 20, sizeof(double) * 4 * 2 * 32);
+            if (training) {
+                KWS_LAUNCH("conv_fwd_clip<16,32>", (conv_fwd_clip_kernel<32, true>), dim3(nblk), dim3(256), sm, s, in, kern, w.z[1], B, Hs[1], Ws[1],
+                           w.partial, kStatStride);
+                fused_stat_blocks = (int)nblk;
+            } else {
+                KWS_LAUNCH("conv_fwd_clip<16,32>", (conv_fwd_clip_kernel<32, false>), dim3(nblk), dim3(256), sm, s, in, kern, w.z[1], B, Hs[1], Ws[1],
+                           w.partial, kStatStride);
+            }
         } else if (l == 2) {
             launch_gemm<32, 64, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s);
         } else {
@@ -175,7 +186,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         if (training) {
             int nblk, rows;
             stat_grid(M, C, nblk, rows);
-            KWS_LAUNCH(prof_name("channel_stats_kernel", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
+            if (fused_stat_blocks) nblk = fused_stat_blocks;
+            else KWS_LAUNCH(prof_name("channel_stats_kernel", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
             KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                                params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
         } else {

@@ -589,9 +589,15 @@ __global__ __launch_bounds__(256) void conv_fwd_clip_kernel(const float *__restr
 }
 
 // dx[b][ih][iw][n] = sum_{tap,c} dz[b][ih+1-kh][iw+1-kw][c] * W[tap][n][c],  CR = c range (conv Cout), CO = 16 (conv Cin)
-template <int CR>
-__global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(const float *__restrict__ dz, const float *__restrict__ wgt,
-                                                               float *__restrict__ dx, int B, int H, int W)
+// BN = true fuses the BatchNorm backward of the layer into the staging: the kernel then reads g (gradient w.r.t. the BN
+// output, in dz) and z (the conv output), forms dz = gamma*inv * (g - k2 - xhat*k3) on the way into LDS and writes it back
+// over g, where the weight-gradient kernel picks it up.
+struct BnBwdArgs {
+    const float *z, *gamma, *mean, *inv, *k2, *k3;
+};
+template <int CR, bool BN>
+__global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(float *__restrict__ dz, const float *__restrict__ wgt,
+                                                               float *__restrict__ dx, int B, int H, int W, BnBwdArgs bn)
 {
     constexpr int CO = 16, JJ = CR / 16, CRP = CR + 4;           // padded pixel stride: spreads ds_read_b128 over the banks
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [(H+2)][(W+2)][CRP], zero halo
@@ -607,33 +613,58 @@ __global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(const float *__res
         for (int jj = 0; jj < JJ; ++jj) wf[t][jj] = *reinterpret_cast<const float4 *>(wgt + ((t * CO + li) * CR + 16 * jj + 4 * lq));
 
     constexpr int F4 = CR / 4;                                    // float4 per pixel
-    constexpr int PF = 8;                                         // float4 held per thread for the next clip (<= 2048 per clip)
+    constexpr int PF = 5;                                         // float4 held per thread for the next clip (<= 1280 per clip)
+    static_assert(256 % F4 == 0, "a thread keeps one channel group for all its float4");
     const int nf4 = HW * F4;
-    float4 pf[PF];
+    float4 pf[PF], pz[PF];
+    // BN coefficients of this thread's 4 channels (c4 = threadIdx.x % F4 for every float4 it stages)
+    float gi[4], mean[4], inv[4], k2[4], k3[4];
+    if (BN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (threadIdx.x % F4) + e;
+            inv[e] = bn.inv[c]; gi[e] = bn.gamma[c] * inv[e]; mean[e] = bn.mean[c]; k2[e] = bn.k2[c]; k3[e] = bn.k3[c];
+        }
+    }
+    auto bn_apply = [&](float4 g, float4 zv) {
+        float4 d;
+        d.x = gi[0] * (g.x - k2[0] - (zv.x - mean[0]) * inv[0] * k3[0]);
+        d.y = gi[1] * (g.y - k2[1] - (zv.y - mean[1]) * inv[1] * k3[1]);
+        d.z = gi[2] * (g.z - k2[2] - (zv.z - mean[2]) * inv[2] * k3[2]);
+        d.w = gi[3] * (g.w - k2[3] - (zv.w - mean[3]) * inv[3] * k3[3]);
+        return d;
+    };
     auto prefetch = [&](int b) {
         const float4 *src = reinterpret_cast<const float4 *>(dz + (long)b * HW * CR);
+        const float4 *zs = reinterpret_cast<const float4 *>(bn.z + (long)b * HW * CR);
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             const int i = threadIdx.x + 256 * j;
             pf[j] = i < nf4 ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BN) pz[j] = i < nf4 ? zs[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     if ((int)blockIdx.x < B) prefetch(blockIdx.x);
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
         __syncthreads();                                          // previous clip's reads are done
+        float4 *dst = reinterpret_cast<float4 *>(dz + (long)b * HW * CR);
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             const int i = threadIdx.x + 256 * j;
             if (i < nf4) {
                 const int pix = i / F4, c4 = i % F4, y = pix / W, x = pix % W;
-                *reinterpret_cast<float4 *>(&tile[((y + 1) * WP + x + 1) * CRP + 4 * c4]) = pf[j];
+                float4 v = pf[j];
+                if (BN) { v = bn_apply(v, pz[j]); dst[i] = v; }
+                *reinterpret_cast<float4 *>(&tile[((y + 1) * WP + x + 1) * CRP + 4 * c4]) = v;
             }
         }
         if (nf4 > 256 * PF) {                                     // larger clips: the remainder goes straight through
-            const float4 *src = reinterpret_cast<const float4 *>(dz + (long)b * HW * CR);
+            const float4 *zs = reinterpret_cast<const float4 *>(bn.z + (long)b * HW * CR);
             for (int i = threadIdx.x + 256 * PF; i < nf4; i += 256) {
                 const int pix = i / F4, c4 = i % F4, y = pix / W, x = pix % W;
-                *reinterpret_cast<float4 *>(&tile[((y + 1) * WP + x + 1) * CRP + 4 * c4]) = src[i];
+                float4 v = dst[i];
+                if (BN) { v = bn_apply(v, zs[i]); dst[i] = v; }
+                *reinterpret_cast<float4 *>(&tile[((y + 1) * WP + x + 1) * CRP + 4 * c4]) = v;
             }
         }
         __syncthreads();

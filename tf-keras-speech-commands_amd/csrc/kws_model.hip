@@ -260,15 +260,19 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         stat_grid(M, C, nblk, rows);
         // the forward applied dropout to a[3]; its mask is re-derived from the seed here
         const float rate = (l == 3 && seed != 0) ? 0.5f : 0.f;
-        if (pool[l])
-            KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
-                       rows, w.partial, rate, slo, shi);
-        else
+        if (pool[l]) {
+            const long NW = (long)B * (Hz[l] / 2) * (Wz[l] / 2);       // one thread per (pool window, channel)
+            stat_grid(NW, C, nblk, rows);
+            KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_pool_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B,
+                       Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);
+        } else
             KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
                        rows, w.partial, rate, slo, shi);
         KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                    grads + m->o_g[l], grads + m->o_b[l], k);
-        if (l == 3)
+        if (l == 1)
+            ;                                                   // fused into conv_dgrad_clip's staging below
+        else if (l == 3)
             KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<true>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
                        params + m->o_g[l], M * C, C);
         else
@@ -277,7 +281,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         const float *in = w.a[l - 1];
         float *dk = grads + m->o_k[l];
         const float *kern = params + m->o_k[l];
-        if (int rc = fork(l)) return rc;                       // dz of layer l is final: wgrad may start on the side stream
+        if (l != 1)
+            if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
             launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);
@@ -298,9 +303,12 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const unsigned nblk = (unsigned)std::min(B, 256 * 3), nblk_d = (unsigned)std::min(B, 256 * 5);   // LDS-limited residency
             const size_t smw = sizeof(float) * ((size_t)(H1 + 2) * (W1 + 2) * 16 + (size_t)((H1 * W1 + 3) / 4) * 4 * stride16(32));
             const size_t smw2 = std::max(smw, sizeof(float) * (size_t)(1024 + 16 * 32));
-            KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);
+            // dgrad forms dz2 from (g, z2) while staging and leaves it in gz[1]; wgrad then overlaps with layer 1's kernels
             const size_t smd = sizeof(float) * (size_t)(H1 + 2) * (W1 + 2) * (32 + 4);
-            KWS_LAUNCH("conv_dgrad_clip<32,16>", conv_dgrad_clip_kernel<32>, dim3(nblk_d), dim3(256), smd, s, w.gz[1], kern, w.da[0], B, H1, W1);
+            const BnBwdArgs bn = {w.z[1], params + m->o_g[1], k.mean, k.inv, k.k2, k.k3};
+            KWS_LAUNCH("conv_dgrad_clip<32,16>", (conv_dgrad_clip_kernel<32, true>), dim3(nblk_d), dim3(256), smd, s, w.gz[1], kern, w.da[0], B, H1, W1, bn);
+            if (int rc = fork(1)) return rc;
+            KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);
         }
     }
     // layer 1: da1 -> (dgamma1, dbeta1, dW1) with conv1 recomputed; no z1-sized tensor is read or written

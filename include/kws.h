@@ -105,6 +105,10 @@ int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int6
  * n_frames = kws_featurize_raw_frames(f, n_samples) = (n_samples - window)/hop + 1 (0 if shorter).
  */
 int kws_featurize_raw_frames(const kws_featurizer *f, int32_t n_samples);
+
+/* Diagnostics: resident blocks (= clips) per compute unit the runtime reports for the float32 featurizer kernel at this
+ * featurizer's LDS size, and that LDS size in bytes.  No reference counterpart; used by tools/ and DESIGN.md. */
+int kws_featurizer_occupancy(const kws_featurizer *f, int *blocks_per_cu, size_t *lds_bytes);
 int kws_featurize_raw(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, int32_t n_samples,
                       float *feat, void *stream);
 

@@ -21,6 +21,10 @@
 #include "kws_common.h"
 #include "kws_device.h"
 
+#ifndef KWS_FEAT_ABLATE
+#define KWS_FEAT_ABLATE 0
+#endif
+
 namespace kws {
 
 constexpr int kWaves = 5;                 // wavefronts per clip (30 default frames -> 6 frames each)
@@ -32,6 +36,7 @@ constexpr float kEps = 2.220446049250313e-16f;  // np.finfo(float).eps, common/b
 struct FeatDev {
     int window_eff, hop, max_samples, n_frames, n_filt, n_out, feature_size, use_delta, nchunks, nnz;
     int chp, n_filt_pad;   // chunk length padded to a multiple of 4 (zero weights); n_filt rounded up to 4 (zero DCT rows)
+    int tail_batch;        // frames whose band sums / DCT one wave evaluates together (lanes = frames x bands)
     float inv_nfft;
     const float2 *tw1;   // [7][64]  W_512^(lane*k1), k1 = 1..7
     const float2 *tw2;   // [7][8]   W_64^(l2*k2a),   k2a = 1..7
@@ -107,26 +112,35 @@ template <> struct Vec2<short> { using type = short2; };
 
 __host__ __device__ inline int round4(int x) { return (x + 3) & ~3; }
 
-// samples of one frame, 8 complex points per lane: z[n] = x[2n] + i x[2n+1], n = lane + 64 j
-template <typename WavT>
-__device__ __forceinline__ void load_frame(float2 (&v)[8], const WavT *__restrict__ src, int base, int pad, int window_eff,
-                                           bool vec_ok, int lane)
+// Complex points J0..J0+3 of the frame at sample `base`: z[n] = x[2n] + i x[2n+1], n = lane + 64 j.  A frame that lies
+// wholly inside the recorded samples (wave-uniform test) takes the branch-free path: one address, immediate offsets.
+template <typename WavT, int J0>
+__device__ __forceinline__ void load_half(float2 (&v)[4], const WavT *__restrict__ src, int base, int pad, int window_eff,
+                                          bool vec_ok, int lane)
 {
-    if (vec_ok) {
+    using V2 = typename Vec2<WavT>::type;
+    if (vec_ok && base >= pad && window_eff >= 1024) {
+        const V2 *p2 = reinterpret_cast<const V2 *>(src + (base - pad)) + lane + 64 * J0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int s0 = 2 * (lane + 64 * j), p0 = base + s0;
+        for (int j = 0; j < 4; ++j) {
+            const V2 t = p2[64 * j];
+            v[j] = make_float2(to_f32(t.x), to_f32(t.y));
+        }
+    } else if (vec_ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s0 = 2 * (lane + 64 * (J0 + j)), p0 = base + s0;
             float2 val = make_float2(0.f, 0.f);
             if (s0 < window_eff && p0 >= pad) {
-                typename Vec2<WavT>::type t = *reinterpret_cast<const typename Vec2<WavT>::type *>(src + (p0 - pad));
+                const V2 t = *reinterpret_cast<const V2 *>(src + (p0 - pad));
                 val = make_float2(to_f32(t.x), to_f32(t.y));
             }
             v[j] = val;
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int s0 = 2 * (lane + 64 * j), p0 = base + s0;
+        for (int j = 0; j < 4; ++j) {
+            const int s0 = 2 * (lane + 64 * (J0 + j)), p0 = base + s0;
             float2 val = make_float2(0.f, 0.f);
             if (s0 < window_eff && p0 >= pad) val.x = to_f32(src[p0 - pad]);
             if (s0 + 1 < window_eff && p0 + 1 >= pad) val.y = to_f32(src[p0 + 1 - pad]);
@@ -135,37 +149,45 @@ __device__ __forceinline__ void load_frame(float2 (&v)[8], const WavT *__restric
     }
 }
 
-// 5 waves/SIMD: the kernel is bound by dependent LDS round trips per frame (in-kernel stamps, tools/feat_stamp.hip),
-// so resident waves matter more than registers; LDS per block is kept under 40 KB for 4 blocks per CU.
+// One block per clip, each wave owns a run of consecutive frames.  The kernel is bound by instruction issue (about 900
+// wave instructions per frame, 5 waves per SIMD), so the structure is chosen to cut instructions rather than bytes:
+//   * consecutive frames overlap by half when hop = n_fft/2: the upper half of frame f is the lower half of frame f+1 and
+//     stays in registers, so a frame costs 4 loads per lane, issued one frame ahead;
+//   * the band sum, log and DCT run once per `tail_batch` frames with lane = (frame, band) / (frame, coefficient), which
+//     keeps ~60 of 64 lanes busy instead of 20; results go straight to global memory (no staging unless use_delta);
+//   * per-lane table entries (chunk start, band span) live in registers, not LDS.
+// LDS per block stays under 40 KB for 4 blocks per CU.
 template <typename WavT>
 __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const WavT *__restrict__ wav, int64_t stride,
                                                                       const int32_t *__restrict__ valid_len, int B,
                                                                       FeatDev c, float *__restrict__ feat)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index is uniform: telling the compiler so keeps the frame loop, its counters and branches in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.x;
     if (b >= B) return;
 
+    const int tb = c.tail_batch;
     float2 *s_fft = reinterpret_cast<float2 *>(smem) + wave * kFftTile;
     float *s_pw = reinterpret_cast<float *>(s_fft);                       // power spectrum aliases the FFT tile
-    float *s_part = reinterpret_cast<float *>(smem + kWaves * kFftTile * 8) + wave * 128;
-    float *s_mel = s_part + 64;
-    unsigned char *blk = smem + kWaves * (kFftTile * 8 + 512);
-    int4 *s_chunks = reinterpret_cast<int4 *>(blk);                        // 64 x 16 B
-    int *s_bcs = reinterpret_cast<int *>(blk + 1024);                      // 68 ints
-    float *s_dct = reinterpret_cast<float *>(blk + 1024 + 272);
+    float *s_part = reinterpret_cast<float *>(smem + kWaves * kFftTile * 8) + wave * (tb * 64 + 64 + 4);   // [tb][64]
+    float *s_mel = s_part + tb * 64;                                       // [tb][n_filt_pad] (<= 64)
+    float *s_en = s_mel + 64;                                              // [tb] (<= 4)
+    float *s_dct = reinterpret_cast<float *>(smem + kWaves * kFftTile * 8) + kWaves * (tb * 64 + 64 + 4);
     float *s_w = s_dct + round4(c.n_filt_pad * c.n_out);
-    float *s_feat = s_w + round4(c.nnz);
-    float2 *s_tw1 = reinterpret_cast<float2 *>(s_feat + round4(c.n_frames * c.n_out));   // [7][64]
-    float2 *s_tw2 = s_tw1 + 7 * 64;                                                       // [7][8]
+    float2 *s_tw1 = reinterpret_cast<float2 *>(s_w + round4(c.nnz));      // [7][64]
+    float2 *s_tw2 = s_tw1 + 7 * 64;                                        // [7][8]
+    int *s_bcs = reinterpret_cast<int *>(s_tw2 + 7 * 8);                   // [n_filt + 1] first chunk of each band (<= 68 ints)
+    float *s_feat = reinterpret_cast<float *>(s_bcs + 68);                 // [n_frames][n_out], only with use_delta
 
-    for (int i = tid; i < c.nchunks; i += kThreads) s_chunks[i] = c.chunks[i];
-    for (int i = tid; i <= c.n_filt; i += kThreads) s_bcs[i] = c.bcs[i];
     for (int i = tid; i < c.n_filt_pad * c.n_out; i += kThreads) s_dct[i] = c.dct[i];
     for (int i = tid; i < c.nnz; i += kThreads) s_w[i] = c.w[i];
     for (int i = tid; i < 7 * 64; i += kThreads) s_tw1[i] = c.tw1[i];
     for (int i = tid; i < 7 * 8; i += kThreads) s_tw2[i] = c.tw2[i];
+    for (int i = tid; i <= c.n_filt; i += kThreads) s_bcs[i] = c.bcs[i];
+    s_mel[lane] = 0.f;                                                     // the zero padding past n_filt is read by the DCT
     __syncthreads();
 
     // clip geometry: keep the head, left-pad zeros (data_utils.py:77-80)
@@ -177,16 +199,36 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
     const WavT *src = wav + (int64_t)b * stride;
     const bool vec_ok = (((pad | c.hop | c.window_eff) & 1) == 0) &&
                         ((reinterpret_cast<uintptr_t>(src) & (2 * sizeof(WavT) - 1)) == 0);
+    const bool reuse = 2 * c.hop == 1024 && c.window_eff == 1024;          // frame f+1 starts with frame f's upper half
 
     const int hi = lane >> 3, lo = lane & 7;
+    // per-lane roles in the batched tail
+    const int chunk_first = lane < c.nchunks ? c.chunks[lane].y : 0;       // gather: lane = one chunk of one band
+    const float r_filt = 1.0f / (float)c.n_filt, r_out = 1.0f / (float)c.n_out;
+    float *dst = feat + (int64_t)b * c.n_frames * c.feature_size;
 
-    float2 vn[8];                       // next frame's samples: their HBM latency hides under this frame's FFT
-    if (wave < c.n_frames) load_frame<WavT>(vn, src, wave * c.hop, pad, c.window_eff, vec_ok, lane);
-    for (int f = wave; f < c.n_frames; f += kWaves) {
+    const int fpw = (c.n_frames + kWaves - 1) / kWaves;
+    const int f_beg = wave * fpw, f_end = f_beg + fpw < c.n_frames ? f_beg + fpw : c.n_frames;
+
+    float2 xl[4], xh[4];                // lower / upper half of the next frame to transform
+    if (f_beg < f_end) {
+        load_half<WavT, 0>(xl, src, f_beg * c.hop, pad, c.window_eff, vec_ok, lane);
+        load_half<WavT, 4>(xh, src, f_beg * c.hop, pad, c.window_eff, vec_ok, lane);
+    }
+    int qi = 0;                          // frames waiting in this wave's tail batch
+    for (int f = f_beg; f < f_end; ++f) {
         float2 v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = vn[j];
-        if (f + kWaves < c.n_frames) load_frame<WavT>(vn, src, (f + kWaves) * c.hop, pad, c.window_eff, vec_ok, lane);
+        for (int j = 0; j < 4; ++j) { v[j] = xl[j]; v[j + 4] = xh[j]; }
+        if (f + 1 < f_end) {             // next frame's samples: their HBM latency hides under this frame's FFT
+            if (reuse) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xl[j] = xh[j];
+            } else {
+                load_half<WavT, 0>(xl, src, (f + 1) * c.hop, pad, c.window_eff, vec_ok, lane);
+            }
+            load_half<WavT, 4>(xh, src, (f + 1) * c.hop, pad, c.window_eff, vec_ok, lane);
+        }
 
         // pass 1: DFT-8 over n1 (n = lane + 64 n1), twiddle W_512^(lane*k1)
         dft8(v);
@@ -199,6 +241,7 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = s_fft[72 * hi + lo + 8 * j];
 
+#if !(KWS_FEAT_ABLATE & 4)
         // pass 2: lane = (k1, l2); DFT-8 over l1, twiddle W_64^(l2*k2a)
         dft8(v);
 #pragma unroll
@@ -212,16 +255,19 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
 
         // pass 3: lane = (k1, k2a); DFT-8 over l2 -> Z[k1 + 8 k2a + 64 k2b]
         dft8(v);
+#endif
         wave_sync();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {       // natural order k = hi + 8 lo + 64 r, stored at k + (k >> 3): the plain index
-            const int k = hi + 8 * lo + 64 * r;   // is a 4-way bank conflict (lo strides 16 words), the padded one 1-2 way
-            s_fft[k + (k >> 3)] = v[r];
+        for (int r = 0; r < 8; ++r) {       // natural order k = hi + 8 lo + 64 r, stored at k + (k >> 3) = hi + 9 lo + 72 r: the
+            s_fft[hi + 9 * lo + 72 * r] = v[r];   // plain index is a 4-way bank conflict (lo strides 16 words), the padded one 1-2 way
         }
         wave_sync();
 
         // real-FFT split: X[k] = E[k] + W_1024^k O[k], X[512-k] = conj(E[k] - W_1024^k O[k])
         float pk[4], pm[4], p256 = 0.f, energy = 0.f;
+#if (KWS_FEAT_ABLATE & 2)
+        for (int i = 0; i < 4; ++i) { pk[i] = v[i].x; pm[i] = v[i].y; energy += v[i + 4].x + v[i + 4].y; }
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = lane + 64 * i;
@@ -240,6 +286,7 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
             p256 = (z.x * z.x + z.y * z.y) * c.inv_nfft;
             energy += p256;
         }
+#endif
         wave_sync();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -252,10 +299,14 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
         wave_sync();
 
         // sparse band gather: lane = one chunk (<= chp bins) of one band's non-zero span.  Fixed trip count over
-        // zero-padded weights so the LDS loads of a group issue back to back (this phase is latency-, not rate-bound).
+        // zero-padded weights so the LDS loads of a group issue back to back.
+#if (KWS_FEAT_ABLATE & 1)
+        if (f + 1 == f_end) dst[f * c.n_out + (lane % c.n_out)] = energy + s_pw[lane];
+        continue;
+#endif
         float part = 0.f;
         if (lane < c.nchunks) {
-            const float *pp = s_pw + s_chunks[lane].y;
+            const float *pp = s_pw + chunk_first;
             const float *wp = s_w + lane * c.chp;
             for (int t = 0; t < c.chp; t += 4) {
                 const float4 wv = *reinterpret_cast<const float4 *>(wp + t);
@@ -266,43 +317,67 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
                 part = fmaf(p3, wv.w, part);
             }
         }
-        s_part[lane] = part;
+        s_part[qi * 64 + lane] = part;
+        if (lane == 0) s_en[qi] = energy;
+        ++qi;
+        if (qi < tb && f + 1 < f_end) continue;
+#if (KWS_FEAT_ABLATE & 8)
         wave_sync();
-        float melv = 0.f;
-        if (lane < c.n_filt) {
-            const int q0 = s_bcs[lane], cnt = s_bcs[lane + 1] - q0;
-            float sum = 0.f;
-            for (int g = 0; g < cnt; g += 8) {
-                float pv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) pv[i] = (g + i < cnt) ? s_part[q0 + g + i] : 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) sum += pv[i];
-            }
-            melv = logf(fmaxf(sum, kEps));                       // safe_log, bark_feature.py:75-77
-        }
-        s_mel[lane] = melv;                                      // lanes >= n_filt store the zero padding
+        if (lane < qi * c.n_out) dst[(f + 1 - qi) * c.n_out + lane] = s_part[lane] + s_en[0];
+        qi = 0;
+        continue;
+#endif
+
+        // ---- tail of the qi frames f-qi+1 .. f: band sums -> log -> DCT, all frames of the batch at once ----
+        // lane roles are recomputed per batch (twice per wave) rather than held in registers across the FFTs;
+        // (lane + 0.5) / n is at least 0.5/64 away from an integer, so the reciprocal multiply floors exactly
+        const int f0 = f + 1 - qi;
+        int tl = lane;                     // opaque copy: keeps the role arithmetic below inside the tail (it is loop-invariant,
+        asm volatile("" : "+v"(tl));     // so the compiler would otherwise hoist it out of the frame loop and spill it)
         wave_sync();
-        if (lane < c.n_out) {
-            float sum = 0.f;
-            for (int n = 0; n < c.n_filt_pad; n += 4) {
-                const float4 mv = *reinterpret_cast<const float4 *>(s_mel + n);
-                const float d0 = s_dct[n * c.n_out + lane], d1 = s_dct[(n + 1) * c.n_out + lane];
-                const float d2 = s_dct[(n + 2) * c.n_out + lane], d3 = s_dct[(n + 3) * c.n_out + lane];
-                sum = fmaf(mv.x, d0, sum);
-                sum = fmaf(mv.y, d1, sum);
-                sum = fmaf(mv.z, d2, sum);
-                sum = fmaf(mv.w, d3, sum);
+        {
+            const int bq = (int)(((float)tl + 0.5f) * r_filt), bm = tl - bq * c.n_filt;       // lane = (frame in batch, band)
+            if (bq < qi) {
+                const int q0 = s_bcs[bm], cnt = s_bcs[bm + 1] - q0;
+                const float *pq = s_part + bq * 64 + q0;
+                float sum = 0.f;
+                for (int g = 0; g < cnt; g += 8) {                       // reads past cnt stay inside s_part / s_mel and are masked
+                    float pv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pv[i] = pq[g + i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) sum += (g + i < cnt) ? pv[i] : 0.f;
+                }
+                s_mel[bq * c.n_filt_pad + bm] = logf(fmaxf(sum, kEps));   // safe_log, bark_feature.py:75-77
             }
-            if (lane == 0) sum = logf(fmaxf(energy, kEps));      // c0 <- log energy, bark_feature.py:173
-            s_feat[f * c.n_out + lane] = sum;
         }
+        wave_sync();
+        {
+            const int dq = (int)(((float)tl + 0.5f) * r_out), dn = tl - dq * c.n_out;         // lane = (frame in batch, coefficient)
+            if (dq < qi) {
+                const float *mq = s_mel + dq * c.n_filt_pad;
+                float sum = 0.f;
+                for (int n = 0; n < c.n_filt_pad; n += 4) {
+                    const float4 mv = *reinterpret_cast<const float4 *>(mq + n);
+                    const float d0 = s_dct[n * c.n_out + dn], d1 = s_dct[(n + 1) * c.n_out + dn];
+                    const float d2 = s_dct[(n + 2) * c.n_out + dn], d3 = s_dct[(n + 3) * c.n_out + dn];
+                    sum = fmaf(mv.x, d0, sum);
+                    sum = fmaf(mv.y, d1, sum);
+                    sum = fmaf(mv.z, d2, sum);
+                    sum = fmaf(mv.w, d3, sum);
+                }
+                if (dn == 0) sum = logf(fmaxf(s_en[dq], kEps));           // c0 <- log energy, bark_feature.py:173
+                if (c.use_delta) s_feat[f0 * c.n_out + tl] = sum;         // lane = dq * n_out + dn
+                else dst[f0 * c.n_out + tl] = sum;                        // feature_size == n_out: rows f0.. are contiguous
+            }
+        }
+        qi = 0;
         wave_sync();
     }
+    if (!c.use_delta) return;
     __syncthreads();
 
-    // coalesced store of the clip's (n_features x feature_size) block; add_deltas fused (data_utils.py:50-58)
-    float *dst = feat + (int64_t)b * c.n_frames * c.feature_size;
+    // add_deltas (data_utils.py:50-58): the clip's (n_features x 2 n_out) block from the staged coefficients
     const int total = c.n_frames * c.feature_size;
     for (int i = tid; i < total; i += kThreads) {
         const int fr = i / c.feature_size, col = i - fr * c.feature_size;
@@ -404,6 +479,13 @@ __global__ __launch_bounds__(kGenWaves * 64) void featurize_generic_kernel(const
 // ---------------------------------------------------------------------------------------------
 // host side: parameter geometry and table construction (double precision, then rounded once)
 // ---------------------------------------------------------------------------------------------
+static size_t feat_smem_bytes(const FeatDev &d)
+{
+    return (size_t)kWaves * (kFftTile * 8 + 4 * (d.tail_batch * 64 + 64 + 4)) +
+           4 * (size_t)(round4(d.n_filt_pad * d.n_out) + round4(d.nnz)) + 8 * (7 * 64 + 7 * 8) + 272 +
+           (d.use_delta ? 4 * (size_t)round4(d.n_frames * d.n_out) : 0);
+}
+
 static int derive(const kws_params *p, kws_geometry *g)
 {
     if (!p || !g) return fail(KWS_ERR_INVALID, "null params");
@@ -615,6 +697,7 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     d.n_filt = n_filt; d.n_out = n_out; d.feature_size = g.feature_size; d.use_delta = p->use_delta ? 1 : 0;
     d.nchunks = (int)chunks.size(); d.nnz = (int)w.size(); d.inv_nfft = 1.0f / (float)p->n_fft;
     d.chp = chp; d.n_filt_pad = n_filt_pad;
+    d.tail_batch = std::max(1, std::min(4, 64 / std::max(n_filt_pad, n_out)));
     d.tw1 = reinterpret_cast<const float2 *>(base + o_tw1);
     d.tw2 = reinterpret_cast<const float2 *>(base + o_tw2);
     d.tws = reinterpret_cast<const float2 *>(base + o_tws);
@@ -629,8 +712,7 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     d.bfirst = reinterpret_cast<const int *>(base + o_bf);
     d.bwidth = reinterpret_cast<const int *>(base + o_bwd);
     d.bw = reinterpret_cast<const float *>(base + o_bw);
-    f->smem_bytes = (size_t)kWaves * (kFftTile * 8 + 512) + 1024 + 272 +
-                    4 * (size_t)(round4(n_filt_pad * n_out) + round4(d.nnz) + round4(n_frames * n_out)) + 8 * (7 * 64 + 7 * 8);
+    f->smem_bytes = feat_smem_bytes(d);
     if (f->smem_bytes > 64 * 1024) {
         (void)hipFree(f->dmem);
         delete f;
@@ -660,12 +742,6 @@ int kws_featurizer_bank(const kws_featurizer *f, float *host_bank, size_t count)
     if (count != f->bank.size()) return fail(KWS_ERR_INVALID, "bank has %zu floats, caller asked for %zu", f->bank.size(), count);
     std::memcpy(host_bank, f->bank.data(), count * sizeof(float));
     return KWS_OK;
-}
-
-static size_t feat_smem_bytes(const FeatDev &d)
-{
-    return (size_t)kWaves * (kFftTile * 8 + 512) + 1024 + 272 +
-           4 * (size_t)(round4(d.n_filt_pad * d.n_out) + round4(d.nnz) + round4(d.n_frames * d.n_out)) + 8 * (7 * 64 + 7 * 8);
 }
 
 static int launch_generic(const FeatDev &d, const void *wav, int wav_dtype, int B, int64_t stride, const int32_t *valid_len,
@@ -729,6 +805,22 @@ int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int6
     if (B == 0) return KWS_OK;
     if (!valid_len && stride < 1) return fail(KWS_ERR_INVALID, "stride must be >= 1 when valid_len is NULL");
     return launch_featurize(f->dev, wav, wav_dtype, B, stride, valid_len, feat, stream);
+}
+
+int kws_featurizer_occupancy(const kws_featurizer *f, int *blocks_per_cu, size_t *lds_bytes)
+{
+    if (!f || !blocks_per_cu) return fail(KWS_ERR_INVALID, "null argument");
+    const bool tuned = f->dev.n_fft == 1024;
+    const size_t smem = tuned ? feat_smem_bytes(f->dev)
+                              : (size_t)kGenWaves * f->dev.n_fft * 8 + kGenWaves * 256 + 4 * (size_t)round4(f->dev.n_frames * f->dev.n_out);
+    if (lds_bytes) *lds_bytes = smem;
+    int nb = 0;
+    if (tuned)
+        KWS_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, featurize_fft1024_kernel<float>, kThreads, smem));
+    else
+        KWS_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, featurize_generic_kernel<float>, kGenWaves * 64, smem));
+    *blocks_per_cu = nb;
+    return KWS_OK;
 }
 
 int kws_featurize_raw_frames(const kws_featurizer *f, int32_t n_samples)

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void conv_fwd_clip_kernel(const float *__restr
 {
     constexpr int CIN = 16, NT = COUT / 16, XP = CIN + 4;          // padded pixel stride (words)
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [(H+2)][(W+2)][XP], zero halo
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lq = lane >> 4;
     const int HP = H + 2, WP = W + 2, HW = H * W, ntile = (HW + 15) / 16;
     for (int i = threadIdx.x; i < HP * WP * XP; i += 256) tile[i] = 0.f;
 

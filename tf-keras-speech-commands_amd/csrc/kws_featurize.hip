@@ -230,6 +230,12 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
             load_half<WavT, 4>(xh, src, (f + 1) * c.hop, pad, c.window_eff, vec_ok, lane);
         }
 
+#if (KWS_FEAT_ABLATE & 16)
+        { float acc = 0.f;
+          for (int j = 0; j < 8; ++j) acc += v[j].x + v[j].y;
+          if (f + 1 == f_end) dst[f * c.n_out + (lane % c.n_out)] = acc;
+          continue; }
+#endif
         // pass 1: DFT-8 over n1 (n = lane + 64 n1), twiddle W_512^(lane*k1)
         dft8(v);
 #pragma unroll

@@ -106,11 +106,12 @@ int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int6
  */
 int kws_featurize_raw_frames(const kws_featurizer *f, int32_t n_samples);
 
+int kws_featurize_raw(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, int32_t n_samples,
+                      float *feat, void *stream);
+
 /* Diagnostics: resident blocks (= clips) per compute unit the runtime reports for the float32 featurizer kernel at this
  * featurizer's LDS size, and that LDS size in bytes.  No reference counterpart; used by tools/ and DESIGN.md. */
 int kws_featurizer_occupancy(const kws_featurizer *f, int *blocks_per_cu, size_t *lds_bytes);
-int kws_featurize_raw(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, int32_t n_samples,
-                      float *feat, void *stream);
 
 /* ------------------------------------------------------------------------
  * Model: replaces the tf.keras objects built by classifier/model.py:14-46
@@ -207,6 +208,48 @@ int kws_confusion_counts(const int32_t *labels, const int32_t *pred, int B, int 
 int kws_sgd_step(float *params, const float *grads, int64_t n, float lr, float grad_scale, void *stream);
 int kws_rmsprop_step(float *params, const float *grads, float *accum, int64_t n, float lr, float rho, float eps,
                      float grad_scale, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Streaming post-processing: replaces the per-chunk work of listen.py for S
+ * concurrent audio streams that advance in lockstep (one chunk each per step):
+ *   Listener.update_vectors   listen.py:96-114   sliding feature matrix
+ *   ThresholdDecoder          listen.py:452-522  logit-normal cumulative table
+ *   TriggerDetector.update    listen.py:525-559  activation counter
+ *   the loop around them      listen.py:350-375  argmax / max / decode / update
+ * New MFCC rows come from kws_featurize_raw() on the carried + new samples.
+ * ------------------------------------------------------------------------ */
+typedef struct kws_decoder kws_decoder;
+
+/* ThresholdDecoder.__init__ (listen.py:467-472): mu_stds is n pairs (mu, std) on the host; the cumulative table
+ * (resolution * out_range float64 entries) is built once in double precision and kept on the device. */
+int kws_decoder_create(const double *mu_stds, int n, double center, int resolution, double min_z, double max_z,
+                       kws_decoder **out);
+void kws_decoder_destroy(kws_decoder *d);
+/* min_out, out_range (= max_out - min_out) and len(cd) */
+int kws_decoder_info(const kws_decoder *d, int32_t *min_out, int32_t *out_range, int64_t *table_len);
+/* host copy of the table `cd` (count must equal table_len) */
+int kws_decoder_table(const kws_decoder *d, double *host_cd, size_t count);
+/* ThresholdDecoder.decode (listen.py:496-508) on n device values.  raw_dtype KWS_RAW_F64: Python-float semantics;
+ * KWS_RAW_F32: the live loop's semantics, where the float32 network output makes numpy evaluate 1/x - 1 in float32. */
+enum { KWS_RAW_F64 = 0, KWS_RAW_F32 = 1 };
+int kws_decoder_decode(const kws_decoder *d, const void *raw, int raw_dtype, double *decoded, int64_t n, void *stream);
+/* ThresholdDecoder.encode (listen.py:510-517), a host-side scalar helper (searchsorted on the host copy of the table) */
+int kws_decoder_encode(const kws_decoder *d, double threshold, double *raw_out);
+
+/* mfccs = concatenate(mfccs[n:], new[-n:]) with n = min(n_rows, F) for every stream (listen.py:107-109):
+ * feat (S, F, D) updated in place from rows (S, n_rows, D). */
+int kws_stream_push_rows(float *feat, const float *rows, int S, int F, int D, int n_rows, void *stream);
+
+/* TriggerDetector.update (listen.py:538-559) for S streams: state (S, 2) int32 = {activation, record_index}, start it
+ * at {0, -1}.  fired[s] = 1 when the prediction activates the stream. */
+int kws_trigger_update(const int32_t *index, const double *score, int S, int background_index, double sensitivity,
+                       int trigger_level, int chunk_size, int32_t *state, int32_t *fired, void *stream);
+
+/* One step of the loop listen.py:361-375 for S streams, fused: probs (S, C) float32 -> index = argmax, score = max,
+ * decoded through `dec` unless the class is background (dec may be NULL: no decoding), then the trigger update above. */
+int kws_stream_postprocess(const kws_decoder *dec, const float *probs, int S, int C, int background_index,
+                           double sensitivity, int trigger_level, int chunk_size, int32_t *state, int32_t *index,
+                           double *score, int32_t *fired, void *stream);
 
 #ifdef __cplusplus
 }

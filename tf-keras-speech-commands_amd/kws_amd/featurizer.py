@@ -59,7 +59,6 @@ class Featurizer(object):
     def occupancy(self):
         """(resident clips per compute unit, LDS bytes per clip) the HIP runtime reports for this featurizer's kernel."""
         nb, lds = ctypes.c_int(0), ctypes.c_size_t(0)
-        self._L.kws_featurizer_occupancy.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_size_t)]
         _l.check(self._L.kws_featurizer_occupancy(self._h, ctypes.byref(nb), ctypes.byref(lds)))
         return nb.value, lds.value
 

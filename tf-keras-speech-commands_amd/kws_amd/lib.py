@@ -41,6 +41,7 @@ class KwsTrainArgs(ctypes.Structure):
 MODEL_KINDS = {"simple_cnn": 0, "simple_cnn_lite": 1, "simple_gru": 2, "simple_lstm": 3}
 BANK_MEL, BANK_BARK = 0, 1
 WAV_F32, WAV_I16 = 0, 1
+RAW_F64, RAW_F32 = 0, 1
 
 _lib = None
 
@@ -88,6 +89,18 @@ def get_lib():
     L.kws_sgd_step.argtypes = [vp, vp, i64, f32, f32, vp]
     L.kws_rmsprop_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, vp]
     L.kws_adam_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp]
+    f64 = ctypes.c_double
+    L.kws_featurizer_occupancy.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_size_t)]
+    L.kws_decoder_create.argtypes = [ctypes.POINTER(f64), i32, f64, i32, f64, f64, ctypes.POINTER(vp)]
+    L.kws_decoder_destroy.argtypes = [vp]
+    L.kws_decoder_destroy.restype = None
+    L.kws_decoder_info.argtypes = [vp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(i64)]
+    L.kws_decoder_table.argtypes = [vp, ctypes.POINTER(f64), ctypes.c_size_t]
+    L.kws_decoder_decode.argtypes = [vp, vp, i32, vp, i64, vp]
+    L.kws_decoder_encode.argtypes = [vp, f64, ctypes.POINTER(f64)]
+    L.kws_stream_push_rows.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    L.kws_trigger_update.argtypes = [vp, vp, i32, i32, f64, i32, i32, vp, vp, vp]
+    L.kws_stream_postprocess.argtypes = [vp, vp, i32, i32, i32, f64, i32, i32, vp, vp, vp, vp, vp]
     L.kws_prof_enable.argtypes = [i32]
     L.kws_prof_report.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.kws_prof_report.restype = i64

@@ -311,13 +311,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
 // (cy, cx): rows of a class share the set of contributing taps, so no zero tap is ever multiplied.
 // ---------------------------------------------------------------------------------------------------------------
 struct DgradClass { int cy, cx, ny, nx; };   // rows of the class: ih = stride*a + cy (a < ny), iw = stride*b + cx (b < nx)
+struct DgradClasses { DgradClass c[4]; };     // one launch covers every class: blockIdx.y selects it (blocks past a class's rows exit)
 
 template <int CR, int CO, int MW, int STRIDE>
 __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__restrict__ dz, const float *__restrict__ wgt,
                                                                  float *__restrict__ dx, const float *__restrict__ zeros,
-                                                                 ConvGeom g, DgradClass cls)
+                                                                 ConvGeom g, DgradClasses classes)
 {
     constexpr int NT = CO / 16, JJ = CR / 16;
+    const DgradClass cls = classes.c[blockIdx.y];
     static_assert(CR % 16 == 0 && CO % 16 == 0, "channel counts must be multiples of 16");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
     const long Mc = (long)g.B * cls.ny * cls.nx;                      // rows of this class

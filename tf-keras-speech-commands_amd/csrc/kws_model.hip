@@ -91,35 +91,91 @@ void launch_gemm(const float *src, const float *w, const float *bias, float *dst
     KWS_LAUNCH(name.c_str(), (conv_gemm_kernel<CR, CO, MODE, EPI>), dim3(blocks_for(M, 64)), dim3(256), 0, s, src, w, bias, dst, g);
 }
 
+// CUs of the current device (cached) and resident blocks per CU of a kernel at a given dynamic LDS size
+static int cu_count()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+template <typename K>
+static int resident_blocks(K kernel, int threads, size_t smem)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, smem) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+    return nb;
+}
+
+// dW += wgrad(x, dz).  The grid is sized so that all blocks are resident at once (ONE round): with more blocks than slots the
+// last round runs on a fraction of the chip (measured on conv4: 990 blocks on 768 slots left the CUs idle 43 % of the time).
 template <int CIN, int COUT, int GPB>
 void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s)
 {
     constexpr int CB = CIN >= 64 ? 64 : CIN;
+    constexpr size_t smem = (4 * 64 * 4 + 16 * COUT) * sizeof(float);
     const long M = (long)g.B * g.Ho * g.Wo;
     const int ngroups = g.KH * g.KW * (CIN / CB), gy = (ngroups + GPB - 1) / GPB;
     const long steps = (M + 3) / 4;                                   // 4-pixel MFMA k-steps
-    // >= 8 steps per wave so the end-of-block tile reduction amortises; <= ~1024 blocks in total
-    const long waves = std::max<long>(4, std::min<long>((steps + 7) / 8, 4L * std::max(1, 1024 / gy)));
-    const int spw = (int)((steps + waves - 1) / waves);
+    static const int occ = resident_blocks(conv_wgrad_direct_kernel<CIN, COUT, GPB>, 256, smem);
+    const long slots = std::max<long>(1, (long)cu_count() * occ / gy); // blocks along x that fit at once
+    // >= 8 steps per wave so the end-of-block tile reduction amortises
+    const long gx_want = std::max<long>(1, std::min<long>(slots, (steps + 4 * 8 - 1) / (4 * 8)));
+    const int spw = (int)((steps + 4 * gx_want - 1) / (4 * gx_want));
     const long gx = (steps + 4L * spw - 1) / (4L * spw);
     static const std::string name = "conv_wgrad<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
-    KWS_LAUNCH(name.c_str(), (conv_wgrad_direct_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), (4 * 64 * 4 + 16 * COUT) * sizeof(float),
+    KWS_LAUNCH(name.c_str(), (conv_wgrad_direct_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), smem,
                s, x, dz, dw, zero_page(), g, spw);
 }
 
-// dx <- dgrad(dz): one launch per stride-parity class of the input pixels
+// dx <- dgrad(dz): ONE launch over every stride-parity class of the input pixels (blockIdx.y = class).  MW (16-row tiles
+// per wave) is picked so that the waves divide evenly over the SIMDs: every SIMD's matrix pipe then runs
+// ceil(waves / SIMDs) * MW tile-times, and the smallest such product wins (ties: the larger MW reuses weights more).
 template <int CR, int CO, int MW, int STRIDE>
-void launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g, hipStream_t s)
+void launch_dgrad_mw(const float *dz, const float *w, float *dx, const ConvGeom &g, const DgradClasses &cls, int ncls, long max_rows,
+                     hipStream_t s)
 {
     static const std::string name = "conv_dgrad<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
+    KWS_LAUNCH(name.c_str(), (conv_dgrad_direct_kernel<CR, CO, MW, STRIDE>), dim3(blocks_for(max_rows, 64 * MW), (unsigned)ncls), dim3(256), 0, s,
+               dz, w, dx, zero_page(), g, cls);
+}
+
+template <int CR, int CO, int STRIDE>
+void launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g, hipStream_t s)
+{
     if (g.KH > 8 * g.stride || g.KW > 8 * g.stride) { fail(KWS_ERR_UNSUPPORTED, "kernel %dx%d too large for the dgrad tap masks", g.KH, g.KW); return; }
-    for (int cy = 0; cy < g.stride; ++cy)
-        for (int cx = 0; cx < g.stride; ++cx) {
+    DgradClasses cls;
+    int ncls = 0;
+    long rows[4] = {0, 0, 0, 0}, max_rows = 0;
+    for (int cy = 0; cy < g.stride && cy < 2; ++cy)
+        for (int cx = 0; cx < g.stride && cx < 2; ++cx) {
             DgradClass c{cy, cx, (g.H - cy + g.stride - 1) / g.stride, (g.W - cx + g.stride - 1) / g.stride};
             if (c.ny <= 0 || c.nx <= 0) continue;
-            const long Mc = (long)g.B * c.ny * c.nx;
-            KWS_LAUNCH(name.c_str(), (conv_dgrad_direct_kernel<CR, CO, MW, STRIDE>), dim3(blocks_for(Mc, 64 * MW)), dim3(256), 0, s, dz, w, dx, zero_page(), g, c);
+            rows[ncls] = (long)g.B * c.ny * c.nx;
+            max_rows = std::max(max_rows, rows[ncls]);
+            cls.c[ncls++] = c;
         }
+    for (int i = ncls; i < 4; ++i) cls.c[i] = DgradClass{0, 0, 0, 0};
+    if (g.stride > 2) { fail(KWS_ERR_UNSUPPORTED, "dgrad is built for strides 1 and 2"); return; }
+    const long simds = 4L * cu_count();
+    int best = 4;
+    long best_cost = -1;
+    for (int mw = 4; mw >= 1; --mw) {
+        long waves = 0;
+        for (int i = 0; i < ncls; ++i) waves += ((rows[i] + 15) / 16 + mw - 1) / mw;
+        const long cost = ((waves + simds - 1) / simds) * mw;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mw; }
+    }
+    switch (best) {
+    case 1: launch_dgrad_mw<CR, CO, 1, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s); break;
+    case 2: launch_dgrad_mw<CR, CO, 2, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s); break;
+    case 3: launch_dgrad_mw<CR, CO, 3, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s); break;
+    default: launch_dgrad_mw<CR, CO, 4, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s); break;
+    }
 }
 
 ConvGeom geom3x3(int B, int H, int W, int stride)
@@ -249,7 +305,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         stat_grid(B, 128, nblk, rows);
         KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
         KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
-        launch_dgrad<128, 128, 2, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
+        launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
     }
     for (int l = 3; l >= 1; --l) {
         const int C = kCh[l + 1];
@@ -292,15 +348,17 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                 KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(8), 0));
                 KWS_HIP_CHECK(hipEventRecord(bucket_event, s));
             }
-            launch_dgrad<128, 64, 4, 1>(w.gz[3], kern, w.da[2], g, s);
+            launch_dgrad<128, 64, 1>(w.gz[3], kern, w.da[2], g, s);
         } else if (l == 2) {
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
             launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2);
-            launch_dgrad<64, 32, 4, 2>(w.gz[2], kern, w.da[1], g, s);
+            launch_dgrad<64, 32, 2>(w.gz[2], kern, w.da[1], g, s);
         } else {
             // conv2 (16 -> 32, 3x3, stride 1): clip-resident kernels, the clip's tiles are staged in LDS once
             const int H1 = Hs[1], W1 = Ws[1];
-            const unsigned nblk = (unsigned)std::min(B, 256 * 3), nblk_d = (unsigned)std::min(B, 256 * 5);   // LDS-limited residency
+            // persistent grids: at most the LDS-limited residency (3 resp. 5 blocks per CU), with an equal share of clips each
+            auto even_grid = [&](int max_blocks) { const int cpb = (B + max_blocks - 1) / max_blocks; return (unsigned)((B + cpb - 1) / cpb); };
+            const unsigned nblk = even_grid(cu_count() * 3), nblk_d = even_grid(cu_count() * 5);
             const size_t smw = sizeof(float) * ((size_t)(H1 + 2) * (W1 + 2) * 16 + (size_t)((H1 * W1 + 3) / 4) * 4 * stride16(32));
             const size_t smw2 = std::max(smw, sizeof(float) * (size_t)(1024 + 16 * 32));
             // dgrad forms dz2 from (g, z2) while staging and leaves it in gz[1]; wgrad then overlaps with layer 1's kernels
@@ -408,7 +466,7 @@ int lite_backward(const kws_model *m, const float *feat, int B, const float *par
         KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
         KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
         launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s);
-        launch_dgrad<128, 128, 2, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
+        launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
     }
     for (int l = 3; l >= 0; --l) {
         const int Cin = kCh[l], C = kCh[l + 1];
@@ -444,13 +502,13 @@ int lite_backward(const kws_model *m, const float *feat, int B, const float *par
             KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, C, grads + m->o_pwb[l]);
             if (l == 3) {
                 launch_wgrad<64, 128, 1>(w.dwo[3], w.gz[3], grads + m->o_pwk[3], g1, s);
-                launch_dgrad<128, 64, 4, 1>(w.gz[3], pwk, w.ddw[3], g1, s);
+                launch_dgrad<128, 64, 1>(w.gz[3], pwk, w.ddw[3], g1, s);
             } else if (l == 2) {
                 launch_wgrad<32, 64, 1>(w.dwo[2], w.gz[2], grads + m->o_pwk[2], g1, s);
-                launch_dgrad<64, 32, 4, 1>(w.gz[2], pwk, w.ddw[2], g1, s);
+                launch_dgrad<64, 32, 1>(w.gz[2], pwk, w.ddw[2], g1, s);
             } else {
                 launch_wgrad<16, 32, 1>(w.dwo[1], w.gz[1], grads + m->o_pwk[1], g1, s);
-                launch_dgrad<32, 16, 4, 1>(w.gz[1], pwk, w.ddw[1], g1, s);
+                launch_dgrad<32, 16, 1>(w.gz[1], pwk, w.ddw[1], g1, s);
             }
         }
         // depthwise 3x3

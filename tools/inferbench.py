@@ -24,3 +24,14 @@ for mt, B in (("simple_cnn_lite", 16384), ("simple_cnn", 4096), ("simple_gru", 1
         print("%-16s B=%5d graph=%-5s %.3f ms  %.2f Mclips/s  (%.1f%% of the 8 TB/s roofline at 64144 B/clip)" % (mt, B, graph, ms, B / ms / 1e3, B / ms / 1e3 * 64144 / 8e6 * 100))
     eager = InferenceSession(dm, feat, B, use_graph=False); eager.wav.copy_(s.wav); eager.run()
     print("   graph == eager:", torch.equal(eager.probs, p1))
+# per-kernel breakdown of the simple_cnn B=4096 inference (eager, HIP-event profiler of the library)
+import kws_amd.lib as L
+spec = ModelSpec("simple_cnn", 36, 30, 20); dm = DeviceModel(spec); dm.set_weights(init_weights(spec, 0))
+s = InferenceSession(dm, feat, 4096, use_graph=False)
+s.wav.copy_(0.1 * torch.randn((4096, 16000), device="cuda"))
+for _ in range(3): s.run()
+L.prof_enable(True)
+for _ in range(10): s.run()
+rep = L.prof_report(); L.prof_enable(False)
+for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"]):
+    print("   %-34s %.4f ms" % (k, v["total_ms"] / 10))

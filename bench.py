@@ -141,28 +141,37 @@ def main():
     wav_np, lab_np = synthetic_batch(B, rank, N_CLASSES)
     wav = torch.from_numpy(wav_np).cuda()
     labels = torch.from_numpy(lab_np).cuda()
-    feat = torch.empty((B, pr.n_features, pr.feature_size), dtype=torch.float32, device="cuda")
+    from kws_amd.pipeline import FeaturePipeline
+    pipe = FeaturePipeline(feat_fn, B, pr.n_features, pr.feature_size)
     step_no = [0]
 
-    def step():
-        step_no[0] += 1
-        feat_fn(wav, out=feat)
-        dm.train_fwd_bwd(feat, labels, dropout_seed=step_no[0], grad_scale=1.0 / world)
-        if dist is not None:
-            dist.all_reduce(dm.grads)      # RCCL sum over xGMI; 540 KB flat buffer
-        dm.adam_step(1e-3)
+    def run_steps(n):
+        # n complete train steps = n featurizations + n (fwd + bwd + all-reduce + Adam), all enqueued inside this call.
+        # The features of batch k+1 are computed on a side stream while batch k trains (kws_amd/pipeline.py); the first
+        # batch of every call is not overlapped with anything.
+        if n <= 0:
+            return
+        pipe.submit(wav)
+        for i in range(n):
+            step_no[0] += 1
+            feat = pipe.take()
+            if i + 1 < n:
+                pipe.submit(wav)                       # next batch's features: concurrent with this step's model work
+            dm.train_fwd_bwd(feat, labels, dropout_seed=step_no[0], grad_scale=1.0 / world)
+            pipe.release()
+            if dist is not None:
+                dist.all_reduce(dm.grads)      # RCCL sum over xGMI; 540 KB flat buffer
+            dm.adam_step(1e-3)
 
     def fence():
         if dist is not None:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -177,8 +186,7 @@ def main():
     if args.profile_steps > 0:
         if rank == 0:
             kws_amd.lib.prof_enable(True)
-        for _ in range(args.profile_steps):
-            step()
+        run_steps(args.profile_steps)
         fence()
     if rank == 0 and args.profile_steps > 0:
         rep = kws_amd.lib.prof_report()

@@ -183,6 +183,9 @@ typedef struct kws_train_args {
     void *bucket_event;         /* NULL or a hipEvent_t recorded on `stream` as soon as the gradients of the LAST
                                    kws_model_grad_split() .. param_count floats are final (they are produced first
                                    by the backward pass), so their all-reduce can overlap the rest of it */
+    void *forward_event;        /* NULL or a hipEvent_t recorded on `stream` once the forward pass and the loss are
+                                   enqueued: work that should share the chip with the backward pass (the next batch's
+                                   featurization) can be ordered after it                                       */
 } kws_train_args;
 int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream);
 /* offset (in floats) that splits `grads` into {late bucket [0, split), early bucket [split, param_count)} */

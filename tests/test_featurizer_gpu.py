@@ -218,3 +218,34 @@ def test_other_fft_sizes_generic_kernel(torch):
                                            err_msg="%s %s clip %d" % (kw, bank, b))
         got16 = Featurizer(p)(torch.from_numpy((a * 32768).astype(np.int16)).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy()
         np.testing.assert_allclose(got16, Featurizer(p)(torch.from_numpy(a.astype(np.float32)).cuda(), torch.from_numpy(lens).cuda()).cpu().numpy(), atol=1e-6)
+
+
+def test_feature_pipeline_matches_direct_calls(torch):
+    """kws_amd/pipeline.py: features computed on the side stream, double buffered, equal the direct call bit for bit, and a
+    buffer is not rewritten before the step that read it was released."""
+    from classifier.params import pr
+    from kws_amd.featurizer import Featurizer
+    from kws_amd.pipeline import FeaturePipeline
+    f = Featurizer(pr)
+    B = 64
+    g = torch.Generator(device="cuda").manual_seed(11)
+    wavs = [0.1 * torch.randn((B, 16000), device="cuda", generator=g) for _ in range(5)]
+    want = [f(w).clone() for w in wavs]
+    pipe = FeaturePipeline(f, B, pr.n_features, pr.feature_size)
+    with pytest.raises(RuntimeError):
+        pipe.take()
+    seen = []
+    pipe.submit(wavs[0])
+    for i in range(5):
+        feat = pipe.take()
+        if i + 1 < 5:
+            pipe.submit(wavs[i + 1])
+        # a long-running consumer of `feat` on the main stream: the pipeline may not overwrite the buffer under it
+        acc = feat.clone()
+        for _ in range(20):
+            acc = acc + 0.0 * feat
+        seen.append(acc)
+        pipe.release()
+    torch.cuda.synchronize()
+    for got, w in zip(seen, want):
+        assert torch.equal(got, w)

@@ -693,6 +693,7 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     rc = run_head(m, a->B, a->params, w.d1, w.loss_i, w.correct_i, a->labels, a->class_weights, a->probs, nullptr, w.dlogits,
                   a->grad_scale / (float)a->B, a->stats, a->ignore_index, s);
     if (rc) return rc;
+    if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
     return lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
                 : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s);
 }

@@ -1,0 +1,58 @@
+"""Input pipelining for the train step: features of batch k+1 are computed on a side stream while batch k trains.
+
+The featurizer is vector-ALU / LDS work and the model's backward pass is matrix-core work, so the two share the chip well.
+Double buffered; a buffer is rewritten only after the train step that read it has finished (its backward pass recomputes
+conv1 from the features, so the read extends to the end of the step).
+"""
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class FeaturePipeline(object):
+    def __init__(self, featurizer, batch, n_features, feature_size, device="cuda"):
+        torch = _torch()
+        self.featurizer = featurizer
+        self.side = torch.cuda.Stream(device=device)
+        self.bufs = [torch.empty((batch, n_features, feature_size), dtype=torch.float32, device=device) for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]      # features of the buffer are complete (recorded on side)
+        self.free = [None, None]                                  # the step that read the buffer is complete (recorded on main)
+        self.n_submitted = 0
+        self.n_taken = 0
+
+    def submit(self, wav, valid_len=None, after=None):
+        """Enqueue the featurization of one batch on the side stream (returns at once).  `after`: an event on the main
+        stream to start behind (e.g. the running step's forward_event, so that the featurizer shares the chip with the
+        matrix-core-bound backward pass rather than with the forward pass); default: everything enqueued so far."""
+        torch = _torch()
+        i = self.n_submitted % 2
+        if after is not None:
+            self.side.wait_event(after)
+        else:
+            self.side.wait_stream(torch.cuda.current_stream())
+        if self.free[i] is not None:
+            self.side.wait_event(self.free[i])
+        with torch.cuda.stream(self.side):
+            self.featurizer(wav, valid_len=valid_len, out=self.bufs[i])
+            self.ready[i].record(self.side)
+        self.n_submitted += 1
+
+    def take(self):
+        """Features of the oldest submitted batch; the current stream waits for them."""
+        torch = _torch()
+        if self.n_taken >= self.n_submitted:
+            raise RuntimeError("take() without a matching submit()")
+        i = self.n_taken % 2
+        torch.cuda.current_stream().wait_event(self.ready[i])
+        self.n_taken += 1
+        return self.bufs[i]
+
+    def release(self):
+        """Call after the work that reads the most recently taken buffer has been enqueued on the current stream."""
+        torch = _torch()
+        i = (self.n_taken - 1) % 2
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.free[i] = ev

@@ -60,6 +60,12 @@ def kernel_models(B, C):
     for k, (pix, kn) in convs.items():
         m["conv_gemm_fwd<%s>" % k] = ("mfma", 2.0 * B * pix * kn)
         m["conv_wgrad<%s>" % k] = ("mfma", 2.0 * B * pix * kn)
+    # conv3 / conv4 / dense run as three-way bf16 splits on the bf16 matrix cores (kws_conv.h: conv_bf16_kernel); the
+    # algorithmic work stays the layer's fp32 MACs (the six partial products per MAC are an implementation detail)
+    for k, fl in (("conv_bf16_fwd<32,64>", 2.0 * B * 12 * 9 * 32 * 64), ("conv_bf16_fwd<64,128>", 2.0 * B * 12 * 9 * 64 * 128),
+                  ("conv_bf16_fwd<128,128>", 2.0 * B * 256 * 128), ("conv_bf16_dgrad<128,64>", 2.0 * B * 12 * 9 * 64 * 128),
+                  ("conv_bf16_dgrad<128,128>", 2.0 * B * 256 * 128)):
+        m[k] = ("mfma", fl)
     # dgrad kernels are named <reduced channels, produced channels>; algorithmic = the useful MACs of the layer
     m["conv_dgrad<32,16>"] = ("mfma", 2.0 * B * 150 * 9 * 16 * 32)
     m["conv_dgrad<64,32>"] = ("mfma", 2.0 * B * 12 * 9 * 32 * 64)         # one launch over the four stride-2 parity classes

@@ -188,6 +188,16 @@ typedef struct kws_train_args {
                                    featurization) can be ordered after it                                       */
 } kws_train_args;
 int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream);
+/* Arithmetic of the GEMM-shaped layers with 32 or more reduced channels (simple_cnn: conv3, conv4, dense).
+ *   KWS_MATRIX_BF16X6 (default): every fp32 operand is carried as h + m + l in bf16 (24 bits) and a product is the six
+ *                      leading partial products on the bf16 matrix cores with fp32 accumulation: fp32-level error at
+ *                      ~2.7x the fp32 matrix rate
+ *   KWS_MATRIX_FP32:   the fp32 MFMA everywhere (bit-identical to an fp32 fmaf chain)
+ * Library-wide; takes effect at the next forward / train call. */
+enum { KWS_MATRIX_FP32 = 0, KWS_MATRIX_BF16X6 = 1 };
+int kws_set_matrix_precision(int mode);
+int kws_get_matrix_precision(void);
+
 /* offset (in floats) that splits `grads` into {late bucket [0, split), early bucket [split, param_count)} */
 int64_t kws_model_grad_split(const kws_model *m);
 

@@ -324,3 +324,38 @@ def test_cnn_full_batch_4096_grids(torch):
         assert rel_err(b2, a) < 1e-4, (t["name"], rel_err(b2, a))
     # and against a fresh single-GPU "two halves" estimate: the head/dense gradients of a 4096 batch are NOT the mean of
     # two 2048 halves (BatchNormalization couples the clips), so no such check is made here.
+
+
+def test_matrix_precision_modes_agree(torch):
+    """KWS_MATRIX_BF16X6 (default: three-way bf16 split on the matrix cores for conv3 / conv4 / dense) against
+    KWS_MATRIX_FP32 (fp32 MFMA everywhere): same probabilities and gradients to fp32 rounding, both inside the oracle
+    tolerances; unknown modes are refused."""
+    from kws_amd import lib as L
+    from oracle import model_oracle as mo
+    C = 36
+    om, dm = build("simple_cnn", C)
+    B = 96
+    x = features(B, 7)
+    y = np.random.default_rng(8).integers(0, C, B)
+    want_loss, _, _ = mo.train_forward_backward(om, x.astype(np.float64), y)
+    want_grads = om.grad_list()
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
+    assert L.get_matrix_precision() == L.MATRIX_BF16X6
+    res = {}
+    try:
+        for mode in (L.MATRIX_BF16X6, L.MATRIX_FP32):
+            L.set_matrix_precision(mode)
+            assert L.get_matrix_precision() == mode
+            probs = dm.train_fwd_bwd(xt, yt, want_probs=True)
+            res[mode] = (probs.cpu().numpy(), [g.copy() for g in dm.get_grads()], float(dm.stats[0].item()) / B)
+        with pytest.raises(L.KwsError):
+            L.set_matrix_precision(7)
+    finally:
+        L.set_matrix_precision(L.MATRIX_BF16X6)
+    (p6, g6, l6), (p32, g32, l32) = res[L.MATRIX_BF16X6], res[L.MATRIX_FP32]
+    assert abs(l6 - l32) < 2e-6 and abs(l6 - want_loss) < 1e-4
+    np.testing.assert_allclose(p6, p32, rtol=0, atol=2e-6)
+    for a, b, w in zip(g6, g32, want_grads):
+        scale = np.abs(w).max() + 1e-12
+        assert np.abs(a - b).max() / scale < 2e-5          # the two arithmetic paths differ by fp32 rounding only
+        assert np.abs(a - w).max() / scale < 2e-4 and np.abs(b - w).max() / scale < 2e-4

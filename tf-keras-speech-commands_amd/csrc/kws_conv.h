@@ -161,6 +161,196 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Split-precision bf16 (kws_device.h: mfma_bf16x6) form of the LDS-tiled product, for layers with >= 32 reduced channels.
+//
+// weight_split_kernel: once per step, every GEMM weight tensor W[tap][ci][co] (HWIO) becomes six bf16 planes
+//   o[0..2] [tap][ci][co]  h / m / l in the ORIGINAL order   (k = co contiguous: the B operand of the data gradient)
+//   t[0..2] [tap][co][ci]  h / m / l TRANSPOSED per tap      (k = ci contiguous: the B operand of the forward product)
+// conv_bf16_kernel<CR, CO, MODE, EPI, RT>: 32*RT rows x all CO columns per block, K chunks of 32 channels (one MFMA depth).
+//   The four waves form a 2 x 2 grid; a wave owns RT row tiles x CO/32 column tiles, so an A fragment read from LDS feeds
+//   CO/32 and a B fragment RT tile products: the first version (one row tile x all columns per wave) re-read the whole B
+//   tile in every wave and was LDS-bound (0.044 ms for conv4 with ALL global loads removed).
+//   A: gathered activation rows, split into h/m/l while they are staged (once per element per block)
+//   B: 16-byte copies of the prepared planes
+//   LDS rows are 32 bf16 + 8 pad (80 B) (ds_read_b128 of a fragment: at most 2-way conflicts in its 16-lane groups).
+//   Measured at B = 4096 (conv4 forward, RT = 3): 0.051 ms against 0.076 for the fp32 LDS-tiled kernel; phase ablation:
+//   staging (split + LDS stores + 2 barriers per chunk) 0.022, MFMA phase 0.022 (= the matrix-pipe rate at 2 waves per
+//   SIMD), global loads 0.007 -- the phases still run one after the other; overlapping them (double-buffered LDS or
+//   direct-to-LDS loads) is the open step.
+//   MODE_FWD   rows = output pixels, source (y*stride + kh - pt, x*stride + kw - pl), B = transposed planes of the layer
+//   MODE_DGRAD rows = input pixels of a STRIDE-1 layer, source (y + pt - kh, x + pl - kw) in the output map, CR = the
+//              layer's output channels, CO = its input channels, B = original-order planes
+// ---------------------------------------------------------------------------------------------------------------
+struct SplitDesc { const float *w; __bf16 *o[3], *t[3]; int taps, ci, co; };
+struct SplitDescs { SplitDesc d[4]; };
+
+__global__ __launch_bounds__(256) void weight_split_kernel(SplitDescs all)
+{
+    const SplitDesc d = all.d[blockIdx.y];
+    const int per = d.ci * d.co, total = d.taps * per;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const float v = d.w[i];
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1, l = (__bf16)(r1 - (float)m);
+        const int tap = i / per, r = i - tap * per, ci = r / d.co, co = r - ci * d.co;
+        const int t = tap * per + co * d.ci + ci;
+        d.o[0][i] = h; d.o[1][i] = m; d.o[2][i] = l;
+        d.t[0][t] = h; d.t[1][t] = m; d.t[2][t] = l;
+    }
+}
+
+struct Bf16Planes { const __bf16 *p[3]; };
+
+// two blocks per CU (LDS: 54 KB at CO = 128): the 256-register budget keeps the 12 accumulator tiles, the 9 A and 3 B
+// fragments and the staged chunk in VGPRs (at the default occupancy target the compiler spilled into the K loop)
+template <int CR, int CO, int MODE, int EPI, int RT>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restrict__ src, Bf16Planes wp, const float *__restrict__ bias,
+                                                         float *__restrict__ dst, ConvGeom g)
+{
+    constexpr int KC = 32, SK = 40;            // chunk depth and LDS row stride in bf16 units
+    constexpr int BM = 32 * RT;                // rows per block: RT row tiles per wave, 2 waves along M
+    constexpr int NT = CO / 16, CT = NT / 2;   // column tiles per wave (2 waves along N)
+    constexpr int CPT = CR / KC;
+    constexpr int NAU = BM * 8 / 256;          // float4 A units per thread (3)
+    constexpr int NBU = CO * 4 / 256;          // 16-byte B units per thread and plane
+    static_assert(CO * 4 % 256 == 0, "every thread stages the same number of B units");
+    static_assert(CR % KC == 0 && CO % 32 == 0, "reduced channels must be a multiple of 32, produced ones of 32");
+    __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * SK], Bs[3][CO * SK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // rows of this product and the map the rows are gathered from
+    const int RH = MODE == MODE_FWD ? g.Ho : g.H, RW = MODE == MODE_FWD ? g.Wo : g.W;
+    const int SH = MODE == MODE_FWD ? g.H : g.Ho, SW = MODE == MODE_FWD ? g.W : g.Wo;
+    const long M = (long)g.B * RH * RW;
+    const long m0 = (long)blockIdx.x * BM;
+    const int ntaps = g.KH * g.KW, nchunks = ntaps * CPT;
+
+    int a_b[NAU], a_y[NAU], a_x[NAU];         // per-thread A-staging coordinates: row = u / 8, float4 c4 = u % 8
+#pragma unroll
+    for (int j = 0; j < NAU; ++j) {
+        const int u = tid + 256 * j;
+        const long m = m0 + u / 8;
+        if (m < M) {
+            const int pix = (int)(m % ((long)RH * RW));
+            a_b[j] = (int)(m / ((long)RH * RW));
+            a_y[j] = pix / RW;
+            a_x[j] = pix % RW;
+        } else {
+            a_b[j] = -1; a_y[j] = 0; a_x[j] = 0;
+        }
+    }
+
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector type: HIP's uint4 struct kept these arrays in scratch
+    struct Staged { f32x4 a[NAU]; u32x4 b[3][NBU]; };
+    auto load_chunk = [&](int chunk, Staged &st) {
+        const int tap = chunk / CPT, c0 = (chunk % CPT) * KC;
+        const int kh = tap / g.KW, kw = tap % g.KW;
+#pragma unroll
+        for (int j = 0; j < NAU; ++j) {
+            const int u = tid + 256 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a_b[j] >= 0) {
+                const int sy = MODE == MODE_FWD ? a_y[j] * g.stride + kh - g.pt : a_y[j] + g.pt - kh;
+                const int sx = MODE == MODE_FWD ? a_x[j] * g.stride + kw - g.pl : a_x[j] + g.pl - kw;
+                if (sy >= 0 && sy < SH && sx >= 0 && sx < SW)
+                    v = *reinterpret_cast<const f32x4 *>(src + (((long)a_b[j] * SH + sy) * SW + sx) * CR + c0 + (u % 8) * 4);
+            }
+            st.a[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NBU; ++j) {
+            const int u = tid + 256 * j;
+            const long e = ((long)(tap * CO + u / 4)) * CR + c0 + 8 * (u % 4);           // plane[tap][col][k]
+#pragma unroll
+            for (int p = 0; p < 3; ++p) st.b[p][j] = *reinterpret_cast<const u32x4 *>(wp.p[p] + e);
+        }
+    };
+    auto store_chunk = [&](const Staged &st) {
+#pragma unroll
+        for (int j = 0; j < NAU; ++j) {
+            const int u = tid + 256 * j;
+            bf16x4 h, m, l;
+            split_bf16(st.a[j], h, m, l);
+            const int o = (u / 8) * SK + 4 * (u % 8);
+            *reinterpret_cast<bf16x4 *>(&As[0][o]) = h;
+            *reinterpret_cast<bf16x4 *>(&As[1][o]) = m;
+            *reinterpret_cast<bf16x4 *>(&As[2][o]) = l;
+        }
+#pragma unroll
+        for (int j = 0; j < NBU; ++j) {
+            const int u = tid + 256 * j;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(&Bs[p][(u / 4) * SK + 8 * (u % 4)]) = st.b[p][j];
+        }
+    };
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto mma_chunk = [&]() {
+        bf16x8 a[RT][3];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[r][p] = *reinterpret_cast<const bf16x8 *>(&As[p][(16 * (wm * RT + r) + li) * SK + 8 * lq]);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8 *>(&Bs[p][(16 * (wn * CT + c) + li) * SK + 8 * lq]);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) acc[r][c] = mfma_bf16x6(a[r], b, acc[r][c]);
+        }
+    };
+
+    // Two chunks of global loads are in flight at any time (two explicit register sets, loop unrolled by two): with two
+    // blocks per CU one MFMA phase (600-1200 cycles) does not cover an L2 miss, two nearly do.
+    Staged s0, s1;
+    load_chunk(0, s0);
+    if (nchunks > 1) load_chunk(1, s1);
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+        __syncthreads();
+        store_chunk(s0);
+        __syncthreads();
+        if (chunk + 2 < nchunks) load_chunk(chunk + 2, s0);
+        mma_chunk();
+        if (chunk + 1 < nchunks) {
+            __syncthreads();
+            store_chunk(s1);
+            __syncthreads();
+            if (chunk + 3 < nchunks) load_chunk(chunk + 3, s1);
+            mma_chunk();
+        }
+    }
+
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n = 16 * (wn * CT + c) + li;
+        float bv = 0.f;
+        if (EPI == EPI_BIAS_RELU6 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bv = bias[n];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long m = m0 + 16 * (wm * RT + rt) + 4 * lq + r;
+                if (m < M) {
+                    float v = acc[rt][c][r];
+                    if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
+                    if (EPI == EPI_BIAS_RELU6) v = relu6f(v + bv);
+                    if (EPI == EPI_BIAS) v = v + bv;
+                    if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
+                    dst[m * CO + n] = v;
+                }
+            }
+    }
+}
+
 // N consecutive floats with the widest aligned load (N = 1, 2, 4, 8); p must be N*4-byte aligned (16 for N = 8)
 template <int N>
 __device__ __forceinline__ void load_vec(const float *__restrict__ p, float (&v)[N])

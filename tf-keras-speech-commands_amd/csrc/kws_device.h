@@ -16,6 +16,37 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// ---- split-precision bf16 on the matrix cores -------------------------------------------------------------------------
+// v_mfma_f32_16x16x32_bf16 (16 cycles, 16x the flops of the fp32 MFMA per cycle): lane l holds A[row l&15][k = 8(l>>4)+j]
+// and B[k = 8(l>>4)+j][col l&15], j = 0..7; C/D as for the fp32 form.  An fp32 value is carried EXACTLY-to-24-bits as
+// h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m) (each residual is exact in fp32), and
+//   a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm)        [dropped: am*bl, al*bm, al*bl < 2^-24 relative]
+// accumulated in fp32, small terms first.  Six MFMAs per product = 96 cycles per 16x16x32 block against 256 for the eight
+// fp32 MFMAs it replaces, at fp32-level error (the two-way split, 3 MFMAs, was measured first: 1e-5 per product, which
+// the BatchNorm-backward cancellations amplified to 2e-3 on the conv1 weight gradient -- not good enough for parity).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf16x6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x4 c)
+{
+    c = mfma_bf16(a[1], b[1], c);
+    c = mfma_bf16(a[2], b[0], c);
+    c = mfma_bf16(a[0], b[2], c);
+    c = mfma_bf16(a[1], b[0], c);
+    c = mfma_bf16(a[0], b[1], c);
+    return mfma_bf16(a[0], b[0], c);
+}
+__device__ __forceinline__ void split_bf16(f32x4 v, bf16x4 &h, bf16x4 &m, bf16x4 &l)
+{
+    h = __builtin_convertvector(v, bf16x4);
+    const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+    m = __builtin_convertvector(r1, bf16x4);
+    l = __builtin_convertvector(r1 - __builtin_convertvector(m, f32x4), bf16x4);
+}
+
 // Counter-based dropout keep decision, bit-identical to oracle/model_oracle.py:dropout_keep
 __device__ __forceinline__ bool dropout_keep(uint32_t seed_lo, uint32_t seed_hi, uint32_t index, float rate)
 {

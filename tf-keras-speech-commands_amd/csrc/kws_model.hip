@@ -33,6 +33,7 @@ struct CnnWs {
     float *z[4], *a[4], *d1, *logits_unused, *loss_i, *correct_i, *dlogits, *dd1, *da4, *gz[4], *da[3];
     float *dwo[4], *ddw[4];   // simple_cnn_lite: depthwise outputs and their gradients
     float *coef[4];     // 6*C floats per BN layer
+    __bf16 *wsp[3][6];  // simple_cnn: bf16 h/m/l planes of conv3, conv4 and dense weights (original order x3, transposed x3; kws_conv.h)
     double *partial;    // [kMaxStatBlocks][2][256]
     size_t bytes;
 };
@@ -57,6 +58,11 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
     w.loss_i = take(B);
     w.correct_i = take(B);
     for (int i = 0; i < 4; ++i) w.coef[i] = take(6 * 128);
+    {
+        const size_t wn[3] = {(size_t)9 * 32 * 64, (size_t)9 * 64 * 128, (size_t)d.flat * 128};
+        for (int t = 0; t < 3; ++t)
+            for (int q = 0; q < 6; ++q) w.wsp[t][q] = reinterpret_cast<__bf16 *>(take(lite ? 0 : (wn[t] + 1) / 2));
+    }
     w.partial = reinterpret_cast<double *>(take((size_t)kMaxStatBlocks * 9 * 64 * 2));   // [9*64 or 2*C rows][kStatStride] doubles
     if (training) {
         w.dlogits = take((size_t)B * m->C);
@@ -178,6 +184,39 @@ void launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g,
     }
 }
 
+// 1 (default): conv3, conv4 and the dense layer run as split-precision bf16 products (kws_device.h: mfma_bf16x6, three-way
+// split, fp32-level error); 0: every product on the fp32 MFMA.  kws_set_matrix_precision() switches it library-wide.
+static int g_matrix_precision = 1;
+
+template <int CR, int CO, int MODE, int EPI>
+void launch_bf16(const char *what, const float *src, __bf16 *const planes[6], const float *bias, float *dst, const ConvGeom &g,
+                 hipStream_t s)
+{
+    const long M = MODE == MODE_FWD ? (long)g.B * g.Ho * g.Wo : (long)g.B * g.H * g.W;
+    static const std::string name = std::string(what) + "<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
+    const int o = MODE == MODE_FWD ? 3 : 0;      // forward reads the transposed planes, the data gradient the original order
+    const Bf16Planes wp{{planes[o], planes[o + 1], planes[o + 2]}};
+    // rows per block = 32 * RT: 96 for conv4's forward (8 column tiles: the larger tile halves the LDS reads per MFMA), 64
+    // elsewhere (3 resident blocks per CU overlap their staging and MFMA phases better; measured per kernel at B = 4096)
+    if (MODE == MODE_FWD && CO == 128 && CR == 64)
+        KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, 3>), dim3(blocks_for(M, 96)), dim3(256), 0, s, src, wp, bias, dst, g);
+    else
+        KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, 2>), dim3(blocks_for(M, 64)), dim3(256), 0, s, src, wp, bias, dst, g);
+}
+
+// h/m/l bf16 planes of the three GEMM weight tensors, once per step (one launch)
+static int split_weights(const kws_model *m, const float *params, CnnWs &w, hipStream_t s)
+{
+    SplitDescs all{};
+    const float *src[3] = {params + m->o_k[2], params + m->o_k[3], params + m->o_dk};
+    const int taps[3] = {9, 9, m->d.H4 * m->d.W4}, ci[3] = {32, 64, 128}, co[3] = {64, 128, 128};
+    for (int t = 0; t < 3; ++t)
+        all.d[t] = SplitDesc{src[t], {w.wsp[t][0], w.wsp[t][1], w.wsp[t][2]}, {w.wsp[t][3], w.wsp[t][4], w.wsp[t][5]}, taps[t], ci[t], co[t]};
+    all.d[3] = all.d[2];
+    KWS_LAUNCH("weight_split_kernel", weight_split_kernel, dim3(64, 3), dim3(256), 0, s, all);
+    return KWS_OK;
+}
+
 ConvGeom geom3x3(int B, int H, int W, int stride)
 {
     ConvGeom g;
@@ -197,6 +236,9 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool pool[4] = {true, true, false, true};
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
 
+    const bool bf16 = g_matrix_precision == 1;
+    if (bf16)
+        if (int rc = split_weights(m, params, w, s)) return rc;
     // layer 1: conv1 is recomputed from the feature map wherever z1 is needed (kws_layer1.h)
     {
         const int cpb = std::max(1, (B + kMaxStatBlocks - 1) / kMaxStatBlocks), nb = (B + cpb - 1) / cpb;
@@ -234,9 +276,12 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                            w.partial, kStatStride);
             }
         } else if (l == 2) {
-            launch_gemm<32, 64, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s);
+            if (bf16) launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s);
+            else launch_gemm<32, 64, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s);
         } else {
-            launch_gemm<64, 128, MODE_FWD, EPI_RELU>(in, kern, nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s);   // activation='relu', cnn.py:55
+            // activation='relu', cnn.py:55
+            if (bf16) launch_bf16<64, 128, MODE_FWD, EPI_RELU>("conv_bf16_fwd", in, w.wsp[1], nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s);
+            else launch_gemm<64, 128, MODE_FWD, EPI_RELU>(in, kern, nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s);
         }
         BnCoef k = coef_of(w.coef[l], C);
         if (training) {
@@ -264,7 +309,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     // Dense(128, use_bias=True) + ReLU6 as a (H4 x W4) 'valid' convolution over the pooled map (Flatten is h,w,c)
     ConvGeom g;
     g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
-    launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s);
+    if (bf16) launch_bf16<128, 128, MODE_FWD, EPI_BIAS_RELU6>("conv_bf16_fwd", w.a[3], w.wsp[2], params + m->o_db, w.d1, g, s);
+    else launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s);
     KWS_LAUNCH_CHECK("simple_cnn forward");
     return KWS_OK;
 }
@@ -305,7 +351,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         stat_grid(B, 128, nblk, rows);
         KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
         KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
-        launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
+        if (g_matrix_precision == 1) launch_bf16<128, 128, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.dd1, w.wsp[2], nullptr, w.da4, g, s);
+        else launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
     }
     for (int l = 3; l >= 1; --l) {
         const int C = kCh[l + 1];
@@ -348,7 +395,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                 KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(8), 0));
                 KWS_HIP_CHECK(hipEventRecord(bucket_event, s));
             }
-            launch_dgrad<128, 64, 1>(w.gz[3], kern, w.da[2], g, s);
+            if (g_matrix_precision == 1) launch_bf16<128, 64, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.gz[3], w.wsp[1], nullptr, w.da[2], g, s);
+            else launch_dgrad<128, 64, 1>(w.gz[3], kern, w.da[2], g, s);
         } else if (l == 2) {
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
             launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2);
@@ -697,6 +745,15 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     return lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
                 : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s);
 }
+
+int kws_set_matrix_precision(int mode)
+{
+    if (mode != KWS_MATRIX_FP32 && mode != KWS_MATRIX_BF16X6) return fail(KWS_ERR_INVALID, "unknown matrix precision %d", mode);
+    g_matrix_precision = mode;
+    return KWS_OK;
+}
+
+int kws_get_matrix_precision(void) { return g_matrix_precision; }
 
 int64_t kws_model_grad_split(const kws_model *m)
 {

@@ -102,6 +102,8 @@ def get_lib():
     L.kws_stream_push_rows.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     L.kws_trigger_update.argtypes = [vp, vp, i32, i32, f64, i32, i32, vp, vp, vp]
     L.kws_stream_postprocess.argtypes = [vp, vp, i32, i32, i32, f64, i32, i32, vp, vp, vp, vp, vp]
+    L.kws_set_matrix_precision.argtypes = [i32]
+    L.kws_get_matrix_precision.restype = i32
     L.kws_prof_enable.argtypes = [i32]
     L.kws_prof_report.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.kws_prof_report.restype = i64
@@ -120,6 +122,18 @@ def version():
 
 def device_count():
     return get_lib().kws_device_count()
+
+
+MATRIX_FP32, MATRIX_BF16X6 = 0, 1
+
+
+def set_matrix_precision(mode):
+    """MATRIX_BF16X6 (default: three-way bf16 split on the matrix cores, fp32-level error) or MATRIX_FP32 (exact fp32 MFMA)."""
+    check(get_lib().kws_set_matrix_precision(int(mode)))
+
+
+def get_matrix_precision():
+    return get_lib().kws_get_matrix_precision()
 
 
 def prof_enable(on=True):

@@ -15,5 +15,5 @@ with contextlib.redirect_stdout(buf):
     bench.main()
 d = json.loads(buf.getvalue().strip().splitlines()[-1])
 print(lib, d["value"], d["ms_per_step"])
-for k, v in list(d["kernel_ms_per_step"].items())[:12]:
+for k, v in list(d.get("kernel_ms_per_step_serial", d["kernel_ms_per_step"]).items())[:int(os.environ.get("KWS_AB_ROWS", "12"))]:
     print("   %-32s %.4f" % (k, v))

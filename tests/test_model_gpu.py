@@ -359,3 +359,80 @@ def test_matrix_precision_modes_agree(torch):
         scale = np.abs(w).max() + 1e-12
         assert np.abs(a - b).max() / scale < 2e-5          # the two arithmetic paths differ by fp32 rounding only
         assert np.abs(a - w).max() / scale < 2e-4 and np.abs(b - w).max() / scale < 2e-4
+
+
+# ---- simple_lstm (classifier/models/rnn.py:46-79): LSTM(48, tanh, dropout 0.2) -> Dense softmax ---------------------------
+def test_lstm_tensor_table(torch):
+    from kws_amd.model import ModelSpec
+    from oracle import model_oracle as mo
+    spec = ModelSpec("simple_lstm", 36, 30, 20)
+    assert spec.trainable_count() == mo.Model("simple_lstm", 36).trainable_count() == 20 * 192 + 48 * 192 + 192 + 48 * 36 + 36
+    assert [t["shape"] for t in spec.tensors] == [(20, 192), (48, 192), (192,), (48, 36), (36,)]
+    assert [t["name"] for t in spec.tensors][:3] == ["lstm_unit_0/kernel", "lstm_unit_0/recurrent_kernel", "lstm_unit_0/bias"]
+
+
+@pytest.mark.parametrize("B", [1, 16, 37])
+def test_lstm_inference_forward(torch, B):
+    om, dm = build("simple_lstm", 36)
+    x = features(B, 113)
+    probs, am = dm.forward(torch.from_numpy(x).cuda())
+    want = om.predict(x.astype(np.float64))
+    np.testing.assert_allclose(probs.cpu().numpy(), want, atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
+
+
+@pytest.mark.parametrize("weighted,seed,B", [(False, 0, 40), (True, 0, 16), (False, 0xBEEF1234, 35)])
+def test_lstm_train_forward_backward(torch, weighted, seed, B):
+    from oracle import model_oracle as mo
+    C = 12
+    om, dm = build("simple_lstm", C)
+    x = features(B, 115)
+    y = np.random.default_rng(116).integers(0, C, B)
+    cw = np.array([0.3] + [0.7 / (C - 1)] * (C - 1)) if weighted else None
+    loss, acc, p = mo.train_forward_backward(om, x.astype(np.float64), y, cw, dropout_seed=seed or None)
+    probs = dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(),
+                             torch.from_numpy(cw.astype(np.float32)).cuda() if weighted else None, dropout_seed=seed,
+                             want_probs=True)
+    stats = dm.stats.cpu().numpy()
+    np.testing.assert_allclose(probs.cpu().numpy(), p, atol=1e-4, rtol=0)
+    assert abs(stats[0] / B - loss) < 1e-4 and stats[1] == round(acc * B)
+    for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
+        assert rel_err(g, want) < 2e-4, "gradient of layer %d %s: rel err %g" % (li, n, rel_err(g, want))
+
+
+def test_lstm_multi_step_training_tracks_oracle(torch):
+    from oracle import model_oracle as mo
+    C, B = 5, 48
+    om, dm = build("simple_lstm", C, seed=4, perturb=False)
+    rng = np.random.default_rng(121)
+    protos = rng.standard_normal((C, 30, 20))
+    opt = mo.Adam(2e-3)
+    for it in range(10):
+        y = rng.integers(0, C, B)
+        x = (protos[y] + 0.5 * rng.standard_normal((B, 30, 20))).astype(np.float32)
+        lo, _ = mo.train_step(om, opt, x.astype(np.float64), y, dropout_seed=700 + it)
+        dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(), dropout_seed=700 + it)
+        dm.adam_step(2e-3)
+        assert abs(float(dm.stats[0].item()) / B - lo) < 1e-3, it
+    for got, want, (li, n, t) in zip(dm.get_weights(), om.get_weights(), om.weight_list()):
+        assert rel_err(got, want) < 2e-3, (li, n)
+
+
+def test_lstm_host_api_fit_learns(torch):
+    from classifier.loss import SparseCategoricalCrossEntropy
+    from classifier.model import get_model
+    from common.model_utils import get_optimizer
+    from kws_amd.init import init_weights
+    rng = np.random.default_rng(5)
+    C, n = 4, 512
+    protos = rng.standard_normal((C, 30, 20)) * 1.5
+    y = rng.integers(0, C, n)
+    x = (protos[y] + 0.6 * rng.standard_normal((n, 30, 20))).astype(np.float32)
+    torch.manual_seed(0)
+    m = get_model("simple_lstm", C)
+    m.set_weights(init_weights(m.spec, seed=1))
+    m.compile(get_optimizer("adam", 5e-3, decay_type=None), SparseCategoricalCrossEntropy(), ["accuracy"])
+    h = m.fit(x, y, batch_size=128, epochs=12, verbose=0, shuffle=True)
+    assert h.history["loss"][-1] < 0.5 * h.history["loss"][0]
+    assert h.history["accuracy"][-1] > 0.9
+    assert m.predict(x[:7]).shape == (7, C)

@@ -627,18 +627,24 @@ int kws_model_create(int kind, int num_classes, int n_features, int feature_size
     if (kind < KWS_SIMPLE_CNN || kind > KWS_SIMPLE_LSTM) return fail(KWS_ERR_INVALID, "Unsupported model type");   // model.py:32
     if (num_classes < 2 || num_classes > 1024) return fail(KWS_ERR_INVALID, "num_classes must be in 2..1024");
     if (n_features < 1 || feature_size < 1) return fail(KWS_ERR_INVALID, "bad input geometry");
-    if (kind == KWS_SIMPLE_LSTM) return fail(KWS_ERR_UNSUPPORTED, "simple_lstm has no HIP kernels yet");
     auto *m = new kws_model();
     m->kind = kind; m->C = num_classes; m->n_features = n_features; m->feature_size = feature_size;
-    if (kind == KWS_SIMPLE_GRU) {
+    if (kind == KWS_SIMPLE_GRU || kind == KWS_SIMPLE_LSTM) {
         if (feature_size > 64) {
             delete m;
-            return fail(KWS_ERR_UNSUPPORTED, "simple_gru supports feature_size <= 64");
+            return fail(KWS_ERR_UNSUPPORTED, "the recurrent models support feature_size <= 64");
         }
-        // GRU(48, activation='linear', dropout=0.2) -> Dense(C, softmax)   (rnn.py:34-35, model.py:37)
-        m->o_rk = m->add("gru_unit_0/kernel", {feature_size, 144}, true);
-        m->o_ru = m->add("gru_unit_0/recurrent_kernel", {48, 144}, true);
-        m->o_rb = m->add("gru_unit_0/bias", {2, 144}, true);
+        if (kind == KWS_SIMPLE_GRU) {
+            // GRU(48, activation='linear', dropout=0.2) -> Dense(C, softmax)   (rnn.py:34-35, model.py:37)
+            m->o_rk = m->add("gru_unit_0/kernel", {feature_size, 144}, true);
+            m->o_ru = m->add("gru_unit_0/recurrent_kernel", {48, 144}, true);
+            m->o_rb = m->add("gru_unit_0/bias", {2, 144}, true);
+        } else {
+            // LSTM(48, activation='tanh', dropout=0.2) -> Dense(C, softmax)    (rnn.py:70-71, model.py:37)
+            m->o_rk = m->add("lstm_unit_0/kernel", {feature_size, 192}, true);
+            m->o_ru = m->add("lstm_unit_0/recurrent_kernel", {48, 192}, true);
+            m->o_rb = m->add("lstm_unit_0/bias", {192}, true);
+        }
         m->head_K = 48;
         m->o_hk = m->add("score_predict/kernel", {48, num_classes}, true);
         m->o_hb = m->add("score_predict/bias", {num_classes}, true);
@@ -704,7 +710,7 @@ int kws_model_tensor_info(const kws_model *m, int index, kws_tensor_info *out)
 int64_t kws_model_workspace_bytes(const kws_model *m, int B, int training)
 {
     if (!m || B < 1) return 0;
-    if (m->kind == KWS_SIMPLE_GRU) return (int64_t)gru_workspace_bytes(m, B, training != 0);
+    if (m->kind == KWS_SIMPLE_GRU || m->kind == KWS_SIMPLE_LSTM) return (int64_t)gru_workspace_bytes(m, B, training != 0);
     return (int64_t)carve_cnn(m, B, training != 0, nullptr).bytes;
 }
 
@@ -713,7 +719,8 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
 {
     if (!m || !feat || !params || !state) return fail(KWS_ERR_INVALID, "null argument");
     if (B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
-    if (m->kind == KWS_SIMPLE_GRU) return gru_forward(m, feat, B, params, ws, ws_bytes, probs, argmax, static_cast<hipStream_t>(stream));
+    if (m->kind == KWS_SIMPLE_GRU || m->kind == KWS_SIMPLE_LSTM)
+        return gru_forward(m, feat, B, params, ws, ws_bytes, probs, argmax, static_cast<hipStream_t>(stream));
     CnnWs w;
     int rc = check_ws(m, B, false, ws, ws_bytes, w);
     if (rc) return rc;
@@ -728,7 +735,7 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
 {
     if (!m || !a || !a->feat || !a->labels || !a->params || !a->state || !a->grads) return fail(KWS_ERR_INVALID, "null argument");
     if (a->B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
-    if (m->kind == KWS_SIMPLE_GRU) return gru_train_fwd_bwd(m, a, static_cast<hipStream_t>(stream));
+    if (m->kind == KWS_SIMPLE_GRU || m->kind == KWS_SIMPLE_LSTM) return gru_train_fwd_bwd(m, a, static_cast<hipStream_t>(stream));
     CnnWs w;
     int rc = check_ws(m, a->B, true, a->ws, a->ws_bytes, w);
     if (rc) return rc;

@@ -1,6 +1,6 @@
-// csrc/kws_rnn.hip -- simple_gru behind the C ABI: GRU(48, linear) -> Dense(C, softmax)
-// (classifier/models/rnn.py:10-43, classifier/model.py:20,27,37).
-#include "kws_gru.h"
+// csrc/kws_rnn.hip -- the recurrent models behind the C ABI: GRU(48, linear) or LSTM(48, tanh) -> Dense(C, softmax)
+// (classifier/models/rnn.py:10-43 and 46-79, classifier/model.py:20-29,37).
+#include "kws_lstm.h"
 #include "kws_model_types.h"
 
 namespace kws {
@@ -20,7 +20,7 @@ GruWs carve_gru(const kws_model *m, int B, bool training, void *base)
     w.loss_i = c.take(B);
     w.correct_i = c.take(B);
     if (training) {
-        w.saved = c.take((size_t)B * m->n_features * kGruSave * kGruU);
+        w.saved = c.take((size_t)B * m->n_features * (m->kind == KWS_SIMPLE_LSTM ? kLstmSave : kGruSave) * kGruU);
         w.dlogits = c.take((size_t)B * m->C);
         w.dh_last = c.take((size_t)B * kGruU);
     }
@@ -45,6 +45,23 @@ int launch_fwd(const kws_model *m, const float *feat, int B, const float *params
     const size_t smem = gru_fwd_smem(T, F);
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
     if (smem > 160 * 1024) return fail(KWS_ERR_UNSUPPORTED, "GRU tile needs %zu B of LDS", smem);
+    if (m->kind == KWS_SIMPLE_LSTM) {
+        if (save) {
+            if (smem > 64 * 1024)
+                KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_fwd_kernel<KX, true>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            KWS_LAUNCH("lstm_fwd_kernel", (lstm_fwd_kernel<KX, true>), dim3(blocks_for(B, 16)), dim3(192), smem, s, feat, params + m->o_rk,
+                       params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi);
+        } else {
+            if (smem > 64 * 1024)
+                KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_fwd_kernel<KX, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            KWS_LAUNCH("lstm_fwd_kernel", (lstm_fwd_kernel<KX, false>), dim3(blocks_for(B, 16)), dim3(192), smem, s, feat, params + m->o_rk,
+                       params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi);
+        }
+        KWS_LAUNCH_CHECK("lstm_fwd_kernel");
+        return KWS_OK;
+    }
     if (save) {
         if (smem > 64 * 1024)
             KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gru_fwd_kernel<KX, true>),
@@ -70,6 +87,15 @@ int launch_bwd(const kws_model *m, const float *feat, int B, const float *params
     const size_t smem = gru_bwd_smem(T, F);
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
     if (smem > 160 * 1024) return fail(KWS_ERR_UNSUPPORTED, "GRU tile needs %zu B of LDS", smem);
+    if (m->kind == KWS_SIMPLE_LSTM) {
+        if (smem > 64 * 1024)
+            KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_kernel<KX>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        KWS_LAUNCH("lstm_bwd_kernel", lstm_bwd_kernel<KX>, dim3(blocks_for(B, 16)), dim3(192), smem, s, feat, params + m->o_ru, w.saved,
+                   w.dh_last, grads + m->o_rk, grads + m->o_ru, grads + m->o_rb, B, T, F, rate, slo, shi);
+        KWS_LAUNCH_CHECK("lstm_bwd_kernel");
+        return KWS_OK;
+    }
     if (smem > 64 * 1024)
         KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gru_bwd_kernel<KX>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
@@ -117,7 +143,7 @@ int gru_train_fwd_bwd(kws_model *m, const kws_train_args *a, hipStream_t s)
     GruWs w;
     int rc = check(m, a->B, true, a->ws, a->ws_bytes, w);
     if (rc) return rc;
-    const float rate = a->dropout_seed != 0 ? 0.2f : 0.f;          // GRU(dropout=0.2): input dropout, rnn.py:34-35
+    const float rate = a->dropout_seed != 0 ? 0.2f : 0.f;          // GRU / LSTM(dropout=0.2): input dropout, rnn.py:34-35,70-71
     rc = dispatch_fwd(m, a->feat, a->B, a->params, w, true, rate, a->dropout_seed, s);
     if (rc) return rc;
     rc = run_head(m, a->B, a->params, w.h_last, w.loss_i, w.correct_i, a->labels, a->class_weights, a->probs, nullptr, w.dlogits,

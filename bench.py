@@ -56,6 +56,10 @@ def kernel_models(B, C):
     m["l1_act_pool_kernel"] = ("hbm", B * (600 + a[0]) * f)
     m["l1_bwd_reduce_kernel"] = ("hbm", B * (600 + a[0]) * f)
     m["l1_bwd_wgrad_kernel"] = ("hbm", B * (600 + a[0]) * f)
+    m["l1m_stats_kernel"] = m["l1_stats_kernel"]                      # the MFMA, wave-per-clip forms of the same passes
+    m["l1m_act_pool_kernel"] = m["l1_act_pool_kernel"]
+    m["l1m_bwd_reduce_kernel"] = m["l1_bwd_reduce_kernel"]
+    m["l1m_bwd_wgrad_kernel"] = m["l1_bwd_wgrad_kernel"]
     convs = {"16,32": (150, 9 * 16 * 32), "32,64": (12, 9 * 32 * 64), "64,128": (12, 9 * 64 * 128), "128,128": (1, 256 * 128)}
     for k, (pix, kn) in convs.items():
         m["conv_gemm_fwd<%s>" % k] = ("mfma", 2.0 * B * pix * kn)

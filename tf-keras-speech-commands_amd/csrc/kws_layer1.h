@@ -226,4 +226,294 @@ __global__ __launch_bounds__(256) void l1_bwd_wgrad_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same four passes on the fp32 MFMA, one WAVE per clip (used when H and W are even, i.e. every pixel lies in a pool
+// window, and the clip has at most 40 tiles).
+//
+// The per-thread kernels above spend one LDS read per FMA (9 reads per output element) and stage every clip behind two
+// block barriers.  Here a 16-pixel x 16-channel tile of z is ONE implicit-GEMM step: A[pixel][tap] (3 LDS reads per lane:
+// taps 4j + lq, j = 0..2, the last three zero) times B[tap][channel] (3 registers per lane for the whole kernel) = 3
+// v_mfma_f32_16x16x4_f32 per 256 outputs.  The 16 pixels of a tile are 4 consecutive pool windows x their 4 elements
+// (pixel p = 4*window + element), so in the D layout (row = 4*lq + r, col = li) lane (li, lq) holds the four elements r of
+// window lq for channel li: pooling, arg-max and the ReLU6 gate stay in registers.  The weight gradient is a second MFMA
+// per element r: A[channel][k = window] = dz_r (already in A layout), B[k = window][tap] = x at that element's tap (one
+// LDS read), D = dW[channel][tap].  fp32 MFMA accumulates the taps in order, so z is the same fmaf chain in all four
+// passes (identical ReLU6 / arg-max decisions between them).
+//
+// Latency, not arithmetic, bounded the first MFMA version (one block per clip sequence: ~10 dependent da1 loads per wave
+// and clip, each a full HBM round trip): a wave now owns whole clips, keeps its zero-haloed map in a private LDS tile (no
+// block barriers), issues ALL of the clip's da1 loads up front and fetches the next clip's map while it computes.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kL1MaxTiles = 40;      // tiles (4 pool windows each) per clip
+constexpr int kL1Group = 10;         // da1 values fetched together, one group ahead of the tiles that use them
+constexpr int kL1Stage = 12;         // staged elements per lane: (H+2)(W+2) <= 64 * 12
+
+struct L1Mma {
+    float wb[3];      // B fragments of the conv1 kernel: W[tap = 4j + lq][c = li], zero for tap >= 9
+    int aoff[3];      // LDS offset of tap 4j + lq from the pixel's patch origin (clamped to tap 8 where the weight is zero)
+    int WP, Wp, nwin, nxs, HW, ntile;
+    int soff[kL1Stage];    // element offset of staged element (lane + 64 j) inside the clip's (H, W) map, -1 = halo / none
+    float pre[kL1Stage];
+    float *xs;             // this wave's (H+2) x (W+2) map
+
+    __device__ __forceinline__ void init(const float *__restrict__ wk, int H, int W, float *smem)
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+        WP = W + 2; Wp = W / 2; nwin = (H / 2) * Wp; nxs = (H + 2) * WP; HW = H * W; ntile = (nwin + 3) / 4;
+        xs = smem + wave * ((nxs + 3) & ~3);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int tap = 4 * j + lq, tc = tap < 9 ? tap : 8;
+            wb[j] = tap < 9 ? wk[tap * 16 + li] : 0.f;
+            aoff[j] = (tc / 3) * WP + tc % 3;
+        }
+#pragma unroll
+        for (int j = 0; j < kL1Stage; ++j) {
+            const int i = lane + 64 * j, r = i / WP - 1, c = i % WP - 1;
+            soff[j] = (i < nxs && r >= 0 && r < H && c >= 0 && c < W) ? r * W + c : -1;
+        }
+    }
+    __device__ __forceinline__ void fetch(const float *__restrict__ feat, long b)
+    {
+#pragma unroll
+        for (int j = 0; j < kL1Stage; ++j) pre[j] = soff[j] >= 0 ? feat[b * HW + soff[j]] : 0.f;
+    }
+    __device__ __forceinline__ void store() const    // wave-private tile: a wave-level fence orders it against the reads
+    {
+        const int lane = threadIdx.x & 63;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < kL1Stage; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nxs) xs[i] = pre[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // z of tile t: lane (li, lq) gets the four elements of window 4t + lq for channel li
+    __device__ __forceinline__ f32x4 z(int t) const
+    {
+        const int lane = threadIdx.x & 63, li = lane & 15;
+        int win = 4 * t + (li >> 2);
+        win = win < nwin ? win : 0;                // windows past the clip are clamped (their results are masked by the caller)
+        const int ph = win / Wp, pw = win - ph * Wp, e = li & 3;
+        const float *base = xs + (2 * ph + (e >> 1)) * WP + 2 * pw + (e & 1);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc = mfma16(base[aoff[j]], wb[j], acc);
+        return acc;
+    }
+};
+
+// clips of this wave: [first, first + count)
+__device__ __forceinline__ void l1m_clips(int B, int clips_per_wave, long &first, int &count)
+{
+    first = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * clips_per_wave;
+    const long left = (long)B - first;
+    count = left <= 0 ? 0 : (left < clips_per_wave ? (int)left : clips_per_wave);
+}
+
+// first arg-max of relu6(y) over the window, and the gradient routed to it (same rule as l1_window above)
+__device__ __forceinline__ void l1m_route(const f32x4 &z, float sc, float sh, float da, int &arg, float &g)
+{
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = fmaf(z[j], sc, sh);
+    arg = 0;
+    float best = relu6f(y[0]);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        const float v = relu6f(y[j]);
+        if (v > best) { best = v; arg = j; }
+    }
+    const float ya = arg == 0 ? y[0] : arg == 1 ? y[1] : arg == 2 ? y[2] : y[3];
+    g = (ya > 0.f && ya < 6.f) ? da : 0.f;
+}
+
+// block-level reduction of two per-lane double sums that belong to channel li: over lq in the wave, then over the 4 waves
+__device__ __forceinline__ void l1m_reduce_store(double s0, double s1, double *__restrict__ partial)
+{
+    __shared__ double red[4][2][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+    if (lq == 0) { red[wave][0][li] = s0; red[wave][1][li] = s1; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int which = threadIdx.x >> 4, c = threadIdx.x & 15;
+        partial[((long)which * 16 + c) * kStatStride + blockIdx.x] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void l1m_stats_kernel(const float *__restrict__ feat, const float *__restrict__ wk, int B, int H,
+                                                         int W, int clips_per_wave, double *__restrict__ partial)
+{
+    extern __shared__ float l1smem[];
+    const int lq = (threadIdx.x & 63) >> 4;
+    L1Mma t;
+    t.init(wk, H, W, l1smem);
+    long first;
+    int count;
+    l1m_clips(B, clips_per_wave, first, count);
+    double s = 0.0, ss = 0.0;
+    if (count > 0) t.fetch(feat, first);
+    for (int i = 0; i < count; ++i) {
+        t.store();
+        if (i + 1 < count) t.fetch(feat, first + i + 1);
+        float fs = 0.f, fss = 0.f;
+        for (int tile = 0; tile < t.ntile; ++tile) {
+            const f32x4 z = t.z(tile);
+            if (4 * tile + lq < t.nwin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { fs += z[r]; fss = fmaf(z[r], z[r], fss); }
+            }
+        }
+        s += (double)fs;
+        ss += (double)fss;
+    }
+    l1m_reduce_store(s, ss, partial);
+}
+
+__global__ __launch_bounds__(256) void l1m_act_pool_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
+                                                            const float *__restrict__ scale, const float *__restrict__ shift,
+                                                            float *__restrict__ a1, int B, int H, int W, int clips_per_wave)
+{
+    extern __shared__ float l1smem[];
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    L1Mma t;
+    t.init(wk, H, W, l1smem);
+    long first;
+    int count;
+    l1m_clips(B, clips_per_wave, first, count);
+    const float sc = scale[li], sh = shift[li];
+    if (count > 0) t.fetch(feat, first);
+    for (int i = 0; i < count; ++i) {
+        t.store();
+        if (i + 1 < count) t.fetch(feat, first + i + 1);
+        float *out = a1 + (first + i) * t.nwin * 16 + li;
+        for (int tile = 0; tile < t.ntile; ++tile) {
+            const f32x4 z = t.z(tile);
+            const float y0 = fmaf(z[0], sc, sh), y1 = fmaf(z[1], sc, sh), y2 = fmaf(z[2], sc, sh), y3 = fmaf(z[3], sc, sh);
+            const int win = 4 * tile + lq;
+            if (win < t.nwin) out[win * 16] = relu6f(fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
+        }
+    }
+}
+
+// (256, 4): four blocks (one wave per clip each) per CU keep all 1024 blocks of a B = 4096 step resident at once
+__global__ __launch_bounds__(256, 4) void l1m_bwd_reduce_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
+                                                              const float *__restrict__ da1, BnCoef k, int B, int H, int W,
+                                                              int clips_per_wave, double *__restrict__ partial)
+{
+    extern __shared__ float l1smem[];
+    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    L1Mma t;
+    t.init(wk, H, W, l1smem);
+    long first;
+    int count;
+    l1m_clips(B, clips_per_wave, first, count);
+    const float sc = k.scale[li], sh = k.shift[li], mean = k.mean[li], inv = k.inv[li];
+    double s = 0.0, sx = 0.0;
+    if (count > 0) t.fetch(feat, first);
+    for (int i = 0; i < count; ++i) {
+        // da1 in groups of kL1Group tiles, fetched one group ahead (all of a group's loads are in flight together)
+        const float *dsrc = da1 + (first + i) * t.nwin * 16 + li;
+        float dcur[kL1Group], dnxt[kL1Group];
+        auto fetch_da = [&](int t0, float (&dv)[kL1Group]) {
+#pragma unroll
+            for (int j = 0; j < kL1Group; ++j) dv[j] = 4 * (t0 + j) + lq < t.nwin ? dsrc[(4 * (t0 + j) + lq) * 16] : 0.f;
+        };
+        fetch_da(0, dnxt);
+        t.store();
+        if (i + 1 < count) t.fetch(feat, first + i + 1);
+        float fs = 0.f, fsx = 0.f;
+        for (int t0 = 0; t0 < t.ntile; t0 += kL1Group) {
+#pragma unroll
+            for (int j = 0; j < kL1Group; ++j) dcur[j] = dnxt[j];
+            if (t0 + kL1Group < t.ntile) fetch_da(t0 + kL1Group, dnxt);
+#pragma unroll
+            for (int j = 0; j < kL1Group; ++j) {
+                const int tile = t0 + j;
+                if (tile < t.ntile) {
+                    const f32x4 z = t.z(tile);
+                    int arg;
+                    float g;
+                    l1m_route(z, sc, sh, dcur[j], arg, g);
+                    const float za = arg == 0 ? z[0] : arg == 1 ? z[1] : arg == 2 ? z[2] : z[3];
+                    fs += g;
+                    fsx = fmaf(g, (za - mean) * inv, fsx);
+                }
+            }
+        }
+        s += (double)fs;
+        sx += (double)fsx;
+    }
+    l1m_reduce_store(s, sx, partial);
+}
+
+__global__ __launch_bounds__(256, 4) void l1m_bwd_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
+                                                             const float *__restrict__ da1, BnCoef k, const float *__restrict__ gamma,
+                                                             float *__restrict__ dw, int B, int H, int W, int clips_per_wave)
+{
+    extern __shared__ float l1smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    L1Mma t;
+    t.init(wk, H, W, l1smem);
+    long first;
+    int count;
+    l1m_clips(B, clips_per_wave, first, count);
+    const float sc = k.scale[li], sh = k.shift[li], mean = k.mean[li], inv = k.inv[li];
+    const float k1 = gamma[li] * inv, k2 = k.k2[li], k3 = k.k3[li];
+    // B side of the weight-gradient MFMA: this lane supplies x at tap li (< 9) of the element's pixel in window 4 tile + lq
+    const int tap = li < 9 ? li : 8, boff = (tap / 3) * t.WP + tap % 3;
+    const float bmask = li < 9 ? 1.f : 0.f;
+    f32x4 accw = {0.f, 0.f, 0.f, 0.f};                 // dW[c = 4 lq + r][tap = li]
+    if (count > 0) t.fetch(feat, first);
+    for (int i = 0; i < count; ++i) {
+        const float *dsrc = da1 + (first + i) * t.nwin * 16 + li;
+        float dcur[kL1Group], dnxt[kL1Group];
+        auto fetch_da = [&](int t0, float (&dv)[kL1Group]) {
+#pragma unroll
+            for (int j = 0; j < kL1Group; ++j) dv[j] = 4 * (t0 + j) + lq < t.nwin ? dsrc[(4 * (t0 + j) + lq) * 16] : 0.f;
+        };
+        fetch_da(0, dnxt);
+        t.store();
+        if (i + 1 < count) t.fetch(feat, first + i + 1);
+        for (int t0 = 0; t0 < t.ntile; t0 += kL1Group) {
+#pragma unroll
+            for (int j = 0; j < kL1Group; ++j) dcur[j] = dnxt[j];
+            if (t0 + kL1Group < t.ntile) fetch_da(t0 + kL1Group, dnxt);
+#pragma unroll
+            for (int j = 0; j < kL1Group; ++j) {
+                const int tile = t0 + j;
+                if (tile < t.ntile) {
+                    const int win = 4 * tile + lq;
+                    const bool ok = win < t.nwin;
+                    const f32x4 z = t.z(tile);
+                    int arg;
+                    float g;
+                    l1m_route(z, sc, sh, dcur[j], arg, g);
+                    const int wq = ok ? win : 0, ph = wq / t.Wp, pw = wq - ph * t.Wp;
+                    const float *xb = t.xs + (2 * ph) * t.WP + 2 * pw + boff;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float dz = k1 * ((r == arg ? g : 0.f) - k2 - (z[r] - mean) * inv * k3);
+                        dz = ok ? dz : 0.f;
+                        accw = mfma16(dz, xb[(r >> 1) * t.WP + (r & 1)] * bmask, accw);
+                    }
+                }
+            }
+        }
+    }
+    __shared__ float shw[4][16][17];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) shw[wave][4 * lq + r][li] = accw[r];
+    __syncthreads();
+    if (threadIdx.x < 9 * 16) {
+        const int tp = threadIdx.x / 16, c = threadIdx.x % 16;
+        atomicAdd(dw + tp * 16 + c, (shw[0][c][tp] + shw[1][c][tp]) + (shw[2][c][tp] + shw[3][c][tp]));
+    }
+}
+
 }  // namespace kws

@@ -243,18 +243,26 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     {
         const int cpb = std::max(1, (B + kMaxStatBlocks - 1) / kMaxStatBlocks), nb = (B + cpb - 1) / cpb;
         const size_t smem1 = sizeof(float) * (size_t)(d.H0 + 2) * (d.W0 + 2);
+        // every pixel in a pool window, a haloed map of at most 768 floats and at most 40 tiles: the MFMA, wave-per-clip forms
+        const bool l1m = d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * kL1Stage &&
+                         (d.H0 / 2) * (d.W0 / 2) <= 4 * kL1MaxTiles;
+        const int cpw = std::max(1, (B + 4 * kMaxStatBlocks - 1) / (4 * kMaxStatBlocks)), nbm = (B + 4 * cpw - 1) / (4 * cpw);
+        const size_t smemm = sizeof(float) * 4 * (size_t)((((d.H0 + 2) * (d.W0 + 2)) + 3) & ~3);
         const long M1 = (long)B * d.H0 * d.W0;
         BnCoef k1 = coef_of(w.coef[0], 16);
         const float *kern1 = params + m->o_k[0];
         if (training) {
-            KWS_LAUNCH("l1_stats_kernel", l1_stats_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, B, d.H0, d.W0, cpb, w.partial);
-            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", 1), bn_finalize_train_kernel, dim3(16), dim3(256), 0, s, w.partial, nb, M1, 16,
+            if (l1m) KWS_LAUNCH("l1m_stats_kernel", l1m_stats_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, B, d.H0, d.W0, cpw, w.partial);
+            else KWS_LAUNCH("l1_stats_kernel", l1_stats_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, B, d.H0, d.W0, cpb, w.partial);
+            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", 1), bn_finalize_train_kernel, dim3(16), dim3(256), 0, s, w.partial, l1m ? nbm : nb, M1, 16,
                        params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1);
         } else {
             KWS_LAUNCH(prof_name("bn_infer_coef_kernel", 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, 16, params + m->o_g[0],
                        params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1);
         }
-        KWS_LAUNCH("l1_act_pool_kernel", l1_act_pool_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
+        if (l1m) KWS_LAUNCH("l1m_act_pool_kernel", l1m_act_pool_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
+                   d.H0, d.W0, cpw);
+        else KWS_LAUNCH("l1_act_pool_kernel", l1_act_pool_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
                    d.H0, d.W0, cpb);
     }
     for (int l = 1; l < 4; ++l) {
@@ -421,14 +429,23 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     {
         const int cpb = std::max(1, (B + kMaxStatBlocks - 1) / kMaxStatBlocks), nb = (B + cpb - 1) / cpb;
         const size_t smem1 = sizeof(float) * (size_t)(d.H0 + 2) * (d.W0 + 2);
+        // every pixel in a pool window, a haloed map of at most 768 floats and at most 40 tiles: the MFMA, wave-per-clip forms
+        const bool l1m = d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * kL1Stage &&
+                         (d.H0 / 2) * (d.W0 / 2) <= 4 * kL1MaxTiles;
+        const int cpw = std::max(1, (B + 4 * kMaxStatBlocks - 1) / (4 * kMaxStatBlocks)), nbm = (B + 4 * cpw - 1) / (4 * cpw);
+        const size_t smemm = sizeof(float) * 4 * (size_t)((((d.H0 + 2) * (d.W0 + 2)) + 3) & ~3);
         const long M1 = (long)B * d.H0 * d.W0;
         BnCoef k1 = coef_of(w.coef[0], 16);
         const float *kern1 = params + m->o_k[0];
-        KWS_LAUNCH("l1_bwd_reduce_kernel", l1_bwd_reduce_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
+        if (l1m) KWS_LAUNCH("l1m_bwd_reduce_kernel", l1m_bwd_reduce_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
+                   cpw, w.partial);
+        else KWS_LAUNCH("l1_bwd_reduce_kernel", l1_bwd_reduce_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
                    cpb, w.partial);
-        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(256), 0, s, w.partial, nb, M1, 16,
+        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(256), 0, s, w.partial, l1m ? nbm : nb, M1, 16,
                    params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], k1);
-        KWS_LAUNCH("l1_bwd_wgrad_kernel", l1_bwd_wgrad_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
+        if (l1m) KWS_LAUNCH("l1m_bwd_wgrad_kernel", l1m_bwd_wgrad_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
+                   grads + m->o_k[0], B, d.H0, d.W0, cpw);
+        else KWS_LAUNCH("l1_bwd_wgrad_kernel", l1_bwd_wgrad_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
                    grads + m->o_k[0], B, d.H0, d.W0, cpb);
     }
     KWS_HIP_CHECK(hipEventRecord(sync_event(9), s2));             // join: every wgrad is part of the caller's stream order again

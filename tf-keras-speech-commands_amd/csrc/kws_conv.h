@@ -205,9 +205,12 @@ struct Bf16Planes { const __bf16 *p[3]; };
 
 // two blocks per CU (LDS: 54 KB at CO = 128): the 256-register budget keeps the 12 accumulator tiles, the 9 A and 3 B
 // fragments and the staged chunk in VGPRs (at the default occupancy target the compiler spilled into the K loop)
-template <int CR, int CO, int MODE, int EPI, int RT>
+// STATS: the epilogue also writes the BatchNorm partial sums of the block's outputs (sum and sum of squares per column, in
+// double) to partial[(which*CO + n)*partial_stride + blockIdx.x], which replaces a separate pass over the conv output.
+template <int CR, int CO, int MODE, int EPI, int RT, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restrict__ src, Bf16Planes wp, const float *__restrict__ bias,
-                                                         float *__restrict__ dst, ConvGeom g)
+                                                         float *__restrict__ dst, ConvGeom g, double *__restrict__ partial = nullptr,
+                                                         int partial_stride = 0)
 {
     constexpr int KC = 32, SK = 40;            // chunk depth and LDS row stride in bf16 units
     constexpr int BM = 32 * RT;                // rows per block: RT row tiles per wave, 2 waves along M
@@ -329,10 +332,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
         }
     }
 
+    float ssum[CT], ssq[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int n = 16 * (wn * CT + c) + li;
         float bv = 0.f;
+        ssum[c] = 0.f; ssq[c] = 0.f;
         if (EPI == EPI_BIAS_RELU6 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bv = bias[n];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -346,8 +351,27 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
                     if (EPI == EPI_BIAS) v = v + bv;
                     if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
                     dst[m * CO + n] = v;
+                    if (STATS) { ssum[c] += v; ssq[c] = fmaf(v, v, ssq[c]); }
                 }
             }
+    }
+    if (STATS) {
+        // lanes with equal li hold the same column: reduce over lq (xor 16, 32), then over the two waves along M through LDS
+        __syncthreads();                                            // the K loop's reads of As are done: reuse it
+        double *red = reinterpret_cast<double *>(&As[0][0]);        // [2 (wm)][2 (which)][CO]
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            double a = (double)ssum[c], q = (double)ssq[c];
+            a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+            q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+            const int n = 16 * (wn * CT + c) + li;
+            if (lq == 0) { red[(wm * 2 + 0) * CO + n] = a; red[(wm * 2 + 1) * CO + n] = q; }
+        }
+        __syncthreads();
+        for (int i = tid; i < 2 * CO; i += 256) {
+            const int which = i / CO, n = i % CO;
+            partial[((long)which * CO + n) * partial_stride + blockIdx.x] = red[(0 * 2 + which) * CO + n] + red[(1 * 2 + which) * CO + n];
+        }
     }
 }
 

@@ -39,10 +39,16 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float *__restr
     const long beg = (long)blockIdx.x * rows_per_block;
     const long end = beg + rows_per_block < M ? beg + rows_per_block : M;
     double s = 0.0, ss = 0.0;
-    for (long m = beg + r; m < end; m += R) {
-        const double v = (double)z[m * C + c];
-        s += v;
-        ss += v * v;
+    for (long m = beg + r; m < end; m += 4 * R) {       // four rows per trip: their loads are issued together
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long mm = m + (long)u * R; v[u] = z[(mm < end ? mm : end - 1) * C + c]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double x = m + (long)u * R < end ? (double)v[u] : 0.0;
+            s += x;
+            ss += x * x;
+        }
     }
     __shared__ double sh[2][256];
     sh[0][threadIdx.x] = s;
@@ -140,9 +146,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
     const long end = beg + rows_per_block < M ? beg + rows_per_block : M;
     const float sc = k.scale[c], sh = k.shift[c], mean = k.mean[c], inv = k.inv[c];
     double s = 0.0, sx = 0.0;
-    for (long m = beg + r; m < end; m += R) {
+    for (long m0 = beg + r; m0 < end; m0 += 4 * R) {    // four rows per trip: their loads are issued together
+      float zv4[4], dv4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                     // unconditional loads on clamped rows: nothing to branch around
+          const long mm = m0 + (long)u * R, mc = mm < end ? mm : end - 1;
+          zv4[u] = z[mc * C + c];
+          dv4[u] = POOL ? 0.f : da[mc * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long m = m0 + (long)u * R;
+        if (m >= end) continue;
         const int pix = (int)(m % ((long)H * W)), b = (int)(m / ((long)H * W)), ih = pix / W, iw = pix % W;
-        const float zv = z[m * C + c];
+        const float zv = zv4[u];
         const float y = fmaf(zv, sc, sh);
         float g = 0.f;
         if (POOL) {
@@ -163,13 +180,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
                 }
             }
         } else {
-            g = da[m * C + c];
+            g = dv4[u];
             if (drop_rate > 0.f) g = dropout_keep(seed_lo, seed_hi, (uint32_t)(m * C + c), drop_rate) ? g / (1.f - drop_rate) : 0.f;
         }
         g = (y > 0.f && y < 6.f) ? g : 0.f;
         gz[m * C + c] = g;
         s += (double)g;
         sx += (double)g * (double)((zv - mean) * inv);
+      }
     }
     __shared__ double shm[2][256];
     shm[0][threadIdx.x] = s;

@@ -188,9 +188,10 @@ void launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g,
 // split, fp32-level error); 0: every product on the fp32 MFMA.  kws_set_matrix_precision() switches it library-wide.
 static int g_matrix_precision = 1;
 
+// returns the number of blocks that wrote BatchNorm partial sums (0: `partial` was not given or the grid exceeds its stride)
 template <int CR, int CO, int MODE, int EPI>
-void launch_bf16(const char *what, const float *src, __bf16 *const planes[6], const float *bias, float *dst, const ConvGeom &g,
-                 hipStream_t s)
+int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], const float *bias, float *dst, const ConvGeom &g,
+                hipStream_t s, double *partial = nullptr)
 {
     const long M = MODE == MODE_FWD ? (long)g.B * g.Ho * g.Wo : (long)g.B * g.H * g.W;
     static const std::string name = std::string(what) + "<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
@@ -198,10 +199,15 @@ void launch_bf16(const char *what, const float *src, __bf16 *const planes[6], co
     const Bf16Planes wp{{planes[o], planes[o + 1], planes[o + 2]}};
     // rows per block = 32 * RT: 96 for conv4's forward (8 column tiles: the larger tile halves the LDS reads per MFMA), 64
     // elsewhere (3 resident blocks per CU overlap their staging and MFMA phases better; measured per kernel at B = 4096)
-    if (MODE == MODE_FWD && CO == 128 && CR == 64)
-        KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, 3>), dim3(blocks_for(M, 96)), dim3(256), 0, s, src, wp, bias, dst, g);
-    else
-        KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, 2>), dim3(blocks_for(M, 64)), dim3(256), 0, s, src, wp, bias, dst, g);
+    constexpr int RT = (MODE == MODE_FWD && CO == 128 && CR == 64) ? 3 : 2;
+    const unsigned nblk = blocks_for(M, 32 * RT);
+    if (partial && (int)nblk <= kStatStride) {
+        KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, true>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, partial,
+                   kStatStride);
+        return (int)nblk;
+    }
+    KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, false>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, nullptr, 0);
+    return 0;
 }
 
 // h/m/l bf16 planes of the three GEMM weight tensors, once per step (one launch)
@@ -284,11 +290,14 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                            w.partial, kStatStride);
             }
         } else if (l == 2) {
-            if (bf16) launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s);
+            // the split-precision kernels write the BatchNorm partial sums from their epilogue when training
+            if (bf16) fused_stat_blocks = launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s,
+                                                                                training ? w.partial : nullptr);
             else launch_gemm<32, 64, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s);
         } else {
             // activation='relu', cnn.py:55
-            if (bf16) launch_bf16<64, 128, MODE_FWD, EPI_RELU>("conv_bf16_fwd", in, w.wsp[1], nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s);
+            if (bf16) fused_stat_blocks = launch_bf16<64, 128, MODE_FWD, EPI_RELU>("conv_bf16_fwd", in, w.wsp[1], nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s,
+                                                                                 training ? w.partial : nullptr);
             else launch_gemm<64, 128, MODE_FWD, EPI_RELU>(in, kern, nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s);
         }
         BnCoef k = coef_of(w.coef[l], C);

@@ -481,7 +481,23 @@ int lite_forward(const kws_model *m, const float *feat, int B, const float *para
     const int strd[4] = {1, 1, 2, 1};
     const bool pool[4] = {true, true, false, true};
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
-    for (int l = 0; l < 4; ++l) {
+    int l_begin = 0;
+    if (!training && d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * 12 && d.H2 >= 1 && d.W2 >= 1) {
+        // inference: stages 1 and 2 fused, one wave per clip, features -> a2 without touching HBM in between (kws_lite.h)
+        BnCoef k0 = coef_of(w.coef[0], 16), k1 = coef_of(w.coef[1], 32);
+        KWS_LAUNCH(prof_name("bn_infer_coef_kernel", 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, 16, params + m->o_g[0], params + m->o_b[0],
+                   state + m->o_mm[0], state + m->o_mv[0], k0);
+        KWS_LAUNCH(prof_name("bn_infer_coef_kernel", 2), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, 32, params + m->o_g[1], params + m->o_b[1],
+                   state + m->o_mm[1], state + m->o_mv[1], k1);
+        const LiteFrontArgs fa = {params + m->o_dwk[0], params + m->o_pwk[0], params + m->o_pwb[0], k0.scale, k0.shift,
+                                  params + m->o_dwk[1], params + m->o_pwk[1], params + m->o_pwb[1], k1.scale, k1.shift};
+        const size_t sm = sizeof(float) * (size_t)lite_front_floats(d.H0, d.W0);
+        const int waves = cu_count() * std::max(1, std::min(8, (int)(160 * 1024 / sm)));
+        const int cpw = std::max(1, (B + waves - 1) / waves), nblk = (B + cpw - 1) / cpw;
+        KWS_LAUNCH("lite_front_infer_kernel", lite_front_infer_kernel, dim3(nblk), dim3(64), sm, s, feat, fa, w.a[1], B, d.H0, d.W0, cpw);
+        l_begin = 2;
+    }
+    for (int l = l_begin; l < 4; ++l) {
         const float *in = l == 0 ? feat : w.a[l - 1];
         const int Cin = kCh[l], C = kCh[l + 1];
         const long M = (long)B * Hz[l] * Wz[l];

@@ -103,6 +103,21 @@ __global__ void bn_infer_coef_kernel(int C, const float *__restrict__ gamma, con
     k.inv[c] = (float)inv;
 }
 
+// the four BatchNorm layers of a CNN forward in one launch (block = layer): inference coefficients are tiny, the launches
+// are what costs
+struct BnInferAll { int C[4]; const float *gamma[4], *beta[4], *mm[4], *mv[4]; BnCoef k[4]; };
+__global__ void bn_infer_coef_all_kernel(BnInferAll a)
+{
+    const int l = blockIdx.x, c = threadIdx.x;
+    if (c >= a.C[l]) return;
+    const double inv = 1.0 / sqrt((double)a.mv[l][c] + (double)kBnEps);
+    const double sc = (double)a.gamma[l][c] * inv;
+    a.k[l].scale[c] = (float)sc;
+    a.k[l].shift[c] = (float)((double)a.beta[l][c] - (double)a.mm[l][c] * sc);
+    a.k[l].mean[c] = a.mm[l][c];
+    a.k[l].inv[c] = (float)inv;
+}
+
 // y = relu6(z*scale + shift), optional 2x2/2 'valid' max-pool, optional inverted dropout on the result
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float *__restrict__ z, const float *__restrict__ scale,

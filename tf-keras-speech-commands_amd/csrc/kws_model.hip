@@ -78,6 +78,20 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
 
 BnCoef coef_of(float *base, int C) { return BnCoef{base, base + C, base + 2 * C, base + 3 * C, base + 4 * C, base + 5 * C}; }
 
+// inference: scale / shift of all four BatchNorm layers in one launch
+static int infer_coefs(const kws_model *m, const float *params, const float *state, CnnWs &w, hipStream_t s)
+{
+    BnInferAll a;
+    for (int l = 0; l < 4; ++l) {
+        a.C[l] = kCh[l + 1];
+        a.gamma[l] = params + m->o_g[l]; a.beta[l] = params + m->o_b[l];
+        a.mm[l] = state + m->o_mm[l]; a.mv[l] = state + m->o_mv[l];
+        a.k[l] = coef_of(w.coef[l], kCh[l + 1]);
+    }
+    KWS_LAUNCH("bn_infer_coef_all_kernel", bn_infer_coef_all_kernel, dim3(4), dim3(128), 0, s, a);
+    return KWS_OK;
+}
+
 // rows-per-block and grid for the (M x C) channel reductions
 inline void stat_grid(long M, int C, int &nblk, int &rows)
 {
@@ -245,6 +259,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool bf16 = g_matrix_precision == 1;
     if (bf16)
         if (int rc = split_weights(m, params, w, s)) return rc;
+    if (!training)
+        if (int rc = infer_coefs(m, params, state, w, s)) return rc;
     // layer 1: conv1 is recomputed from the feature map wherever z1 is needed (kws_layer1.h)
     {
         const int cpb = std::max(1, (B + kMaxStatBlocks - 1) / kMaxStatBlocks), nb = (B + cpb - 1) / cpb;
@@ -262,9 +278,6 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             else KWS_LAUNCH("l1_stats_kernel", l1_stats_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, B, d.H0, d.W0, cpb, w.partial);
             KWS_LAUNCH(prof_name("bn_finalize_train_kernel", 1), bn_finalize_train_kernel, dim3(16), dim3(256), 0, s, w.partial, l1m ? nbm : nb, M1, 16,
                        params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1);
-        } else {
-            KWS_LAUNCH(prof_name("bn_infer_coef_kernel", 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, 16, params + m->o_g[0],
-                       params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1);
         }
         if (l1m) KWS_LAUNCH("l1m_act_pool_kernel", l1m_act_pool_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
                    d.H0, d.W0, cpw);
@@ -308,9 +321,6 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             else KWS_LAUNCH(prof_name("channel_stats_kernel", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
             KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                                params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
-        } else {
-            KWS_LAUNCH(prof_name("bn_infer_coef_kernel", l + 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, C, params + m->o_g[l], params + m->o_b[l],
-                               state + m->o_mm[l], state + m->o_mv[l], k);
         }
         const float rate = (training && l == 3 && seed != 0) ? 0.5f : 0.f;   // Dropout(0.5) after Flatten, cnn.py:63
         if (pool[l]) {
@@ -482,13 +492,11 @@ int lite_forward(const kws_model *m, const float *feat, int B, const float *para
     const bool pool[4] = {true, true, false, true};
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
     int l_begin = 0;
+    if (!training)
+        if (int rc = infer_coefs(m, params, state, w, s)) return rc;
     if (!training && d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * 12 && d.H2 >= 1 && d.W2 >= 1) {
         // inference: stages 1 and 2 fused, one wave per clip, features -> a2 without touching HBM in between (kws_lite.h)
         BnCoef k0 = coef_of(w.coef[0], 16), k1 = coef_of(w.coef[1], 32);
-        KWS_LAUNCH(prof_name("bn_infer_coef_kernel", 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, 16, params + m->o_g[0], params + m->o_b[0],
-                   state + m->o_mm[0], state + m->o_mv[0], k0);
-        KWS_LAUNCH(prof_name("bn_infer_coef_kernel", 2), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, 32, params + m->o_g[1], params + m->o_b[1],
-                   state + m->o_mm[1], state + m->o_mv[1], k1);
         const LiteFrontArgs fa = {params + m->o_dwk[0], params + m->o_pwk[0], params + m->o_pwb[0], k0.scale, k0.shift,
                                   params + m->o_dwk[1], params + m->o_pwk[1], params + m->o_pwb[1], k1.scale, k1.shift};
         const size_t sm = sizeof(float) * (size_t)lite_front_floats(d.H0, d.W0);
@@ -517,9 +525,6 @@ int lite_forward(const kws_model *m, const float *feat, int B, const float *para
             KWS_LAUNCH(prof_name("channel_stats_kernel", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
             KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C,
                        params + m->o_g[l], params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
-        } else {
-            KWS_LAUNCH(prof_name("bn_infer_coef_kernel", l + 1), bn_infer_coef_kernel, dim3(1), dim3(128), 0, s, C, params + m->o_g[l],
-                       params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
         }
         const float rate = (training && l == 3 && seed != 0) ? 0.5f : 0.f;
         if (pool[l])

@@ -255,6 +255,9 @@ def main():
                "config": {"workload": "configs[1]: simple_cnn train step = featurize(f32 1 s @16 kHz) + fwd + bwd + Adam, "
                                       "36 logits (background + 35 words), batch %d per GPU" % B,
                           "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
+                          "matrix_precision": "conv3/conv4/dense as three-way bf16 splits on the bf16 matrix cores with fp32 "
+                                              "accumulation (fp32-level error, kws_set_matrix_precision); everything else fp32",
+                          "input_pipeline": "features of batch k+1 computed on a side stream during step k (all K inside the timed region)",
                           "train_step_hbm_roofline_frac": round(value / world * 229.8e3 / (HBM_PEAK_GBS * 1e9), 4)},
                "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
                "kernel_ms_per_step_serial": breakdown_serial}

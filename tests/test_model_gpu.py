@@ -447,3 +447,27 @@ def test_lstm_host_api_fit_learns(torch):
     assert h.history["loss"][-1] < 0.5 * h.history["loss"][0]
     assert h.history["accuracy"][-1] > 0.9
     assert m.predict(x[:7]).shape == (7, C)
+
+
+@pytest.mark.parametrize("B", [1, 3, 17, 65, 97, 193])
+def test_cnn_train_odd_batch_sizes(torch, B):
+    """Batches that do not fill the kernels' tiles (96- and 64-row blocks of the split-precision products, 4 clips per
+    layer-1 block, 16 samples per head block, the clip kernels' grids): loss, probabilities and every gradient against the
+    oracle, dropout on."""
+    from oracle import model_oracle as mo
+    C = 7
+    om, dm = build("simple_cnn", C, seed=B)
+    x = features(B, 300 + B)
+    y = np.random.default_rng(B).integers(0, C, B)
+    seed = 0x5EED0000 + B
+    loss, acc, p = mo.train_forward_backward(om, x.astype(np.float64), y, dropout_seed=seed)
+    probs = dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(), dropout_seed=seed, want_probs=True)
+    np.testing.assert_allclose(probs.cpu().numpy(), p, atol=1e-4, rtol=0)
+    assert abs(float(dm.stats[0].item()) / B - loss) < 1e-4
+    for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
+        assert rel_err(g, want) < 3e-4, (B, li, n, rel_err(g, want))
+    # and inference on the same batch
+    pi, am = dm.forward(torch.from_numpy(x).cuda())
+    want = om.predict(x.astype(np.float64))
+    np.testing.assert_allclose(pi.cpu().numpy(), want, atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))

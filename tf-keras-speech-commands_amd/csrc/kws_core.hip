@@ -55,7 +55,13 @@ DevRes *dev_res()
     std::lock_guard<std::mutex> lk(mu);
     DevRes &r = res[dev];
     if (!r.side) {
-        if (hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        {
+            // lowest priority: the side stream carries the weight-gradient kernels, which must not delay the small kernels of
+            // the caller's (critical-path) stream when both have work queued
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+            if (hipStreamCreateWithPriority(&r.side, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
+        }
         for (auto &e : r.ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
     }

@@ -180,9 +180,10 @@ typedef struct kws_train_args {
     float grad_scale;
     float *probs;               /* NULL or (B, C)                                                   */
     float *stats;               /* NULL or 2 floats: {sum of per-sample losses, number of top-1 hits} */
-    void *bucket_event;         /* NULL or a hipEvent_t recorded on `stream` as soon as the gradients of the LAST
-                                   kws_model_grad_split() .. param_count floats are final (they are produced first
-                                   by the backward pass), so their all-reduce can overlap the rest of it */
+    void *bucket_event;         /* NULL or a hipEvent_t recorded (possibly on a library-internal stream) as soon as the
+                                   gradients of the LAST kws_model_grad_split() .. param_count floats are final (they are
+                                   produced first by the backward pass): a stream that waits on it may all-reduce that
+                                   bucket while the rest of the backward pass runs */
     void *forward_event;        /* NULL or a hipEvent_t recorded on `stream` once the forward pass and the loss are
                                    enqueued: work that should share the chip with the backward pass (the next batch's
                                    featurization) can be ordered after it                                       */

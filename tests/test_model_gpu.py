@@ -471,3 +471,25 @@ def test_cnn_train_odd_batch_sizes(torch, B):
     want = om.predict(x.astype(np.float64))
     np.testing.assert_allclose(pi.cpu().numpy(), want, atol=1e-4, rtol=0)
     np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
+
+
+def test_bucket_event_marks_final_early_gradients(torch):
+    """kws_train_args.bucket_event: a stream that waits on it sees the early gradient bucket grads[split:] (conv4, BN4, dense,
+    head) in its final state while the rest of the backward pass is still running."""
+    C, B = 36, 2048
+    om, dm = build("simple_cnn", C)
+    x = torch.from_numpy(features(B, 5)).cuda()
+    y = torch.from_numpy(np.random.default_rng(6).integers(0, C, B).astype(np.int32)).cuda()
+    split = dm.grad_split
+    assert 0 < split < dm.grads.numel() and (dm.grads.numel() - split) > 4 * split       # the early bucket is the large one
+    other = torch.cuda.Stream()
+    snap = torch.empty(dm.grads.numel() - split, dtype=torch.float32, device="cuda")
+    for it in range(3):
+        ev = torch.cuda.Event()
+        dm.train_fwd_bwd(x, y, dropout_seed=it + 1, bucket_event=ev)
+        other.wait_event(ev)
+        with torch.cuda.stream(other):
+            snap.copy_(dm.grads[split:])                   # taken as soon as the event fires
+        torch.cuda.synchronize()
+        assert torch.equal(snap, dm.grads[split:]), it     # nothing in the early bucket changed afterwards
+        assert float(snap.abs().sum()) > 0

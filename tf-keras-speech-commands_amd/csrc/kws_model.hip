@@ -425,10 +425,11 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
             launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);
             if (bucket_event) {
-                // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here
-                KWS_HIP_CHECK(hipEventRecord(sync_event(8), s2));
-                KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(8), 0));
-                KWS_HIP_CHECK(hipEventRecord(bucket_event, s));
+                // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here: it
+                // runs the dense and conv4 weight gradients in order and joined the caller's stream at fork(3), i.e. after
+                // head_bwd, the dense bias sums and BN4's backward.  Recorded on the side stream, so the caller's stream does
+                // not wait for the conv4 wgrad.
+                KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
             }
             if (g_matrix_precision == 1) launch_bf16<128, 64, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.gz[3], w.wsp[1], nullptr, w.da[2], g, s);
             else launch_dgrad<128, 64, 1>(w.gz[3], kern, w.da[2], g, s);

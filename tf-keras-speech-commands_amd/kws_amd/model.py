@@ -157,6 +157,9 @@ class DeviceModel(object):
         a.dropout_seed, a.grad_scale = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, float(grad_scale)
         a.probs = probs.data_ptr() if want_probs else None
         a.stats = self.stats.data_ptr()
+        for ev in (bucket_event, forward_event):
+            if ev is not None and not ev.cuda_event:
+                ev.record()                     # torch creates the hipEvent_t lazily; an un-recorded Event has no handle yet
         a.bucket_event = bucket_event.cuda_event if bucket_event is not None else None
         a.forward_event = forward_event.cuda_event if forward_event is not None else None
         _l.check(self._L.kws_model_train_fwd_bwd(self.spec.handle, ctypes.byref(a), torch.cuda.current_stream().cuda_stream))

@@ -257,7 +257,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
 
     const bool bf16 = g_matrix_precision == 1;
-    if (bf16) {
+    if (bf16 && training) {
         // the h/m/l planes are first needed by conv3: split on the side stream beside layers 1-2, join before conv3
         hipStream_t s2 = side_stream();
         if (!s2) return fail(KWS_ERR_HIP, "cannot create the internal side stream");
@@ -265,6 +265,10 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         KWS_HIP_CHECK(hipStreamWaitEvent(s2, sync_event(10), 0));
         if (int rc = split_weights(m, params, w, s2)) return rc;
         KWS_HIP_CHECK(hipEventRecord(sync_event(11), s2));
+    } else if (bf16) {
+        // inference stays on ONE stream: callers capture it into hipGraphs, and a fork to the library's side stream inside
+        // several captured graphs made every graph after the first replay 0.2 ms slower
+        if (int rc = split_weights(m, params, w, s)) return rc;
     }
     if (!training)
         if (int rc = infer_coefs(m, params, state, w, s)) return rc;
@@ -310,7 +314,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                            w.partial, kStatStride);
             }
         } else if (l == 2) {
-            if (bf16) KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(11), 0));     // the weight planes are ready
+            if (bf16 && training) KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(11), 0));     // the weight planes are ready
             // the split-precision kernels write the BatchNorm partial sums from their epilogue when training
             if (bf16) fused_stat_blocks = launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s,
                                                                                 training ? w.partial : nullptr);

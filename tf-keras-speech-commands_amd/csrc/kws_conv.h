@@ -25,7 +25,8 @@ struct ConvGeom {
     int KH, KW;
 };
 
-enum { EPI_NONE = 0, EPI_RELU = 1, EPI_BIAS_RELU6 = 2, EPI_BIAS = 3, EPI_BIAS_RELU = 4 };
+enum { EPI_NONE = 0, EPI_RELU = 1, EPI_BIAS_RELU6 = 2, EPI_BIAS = 3, EPI_BIAS_RELU = 4,
+       EPI_BN_RELU6 = 5 };   // inference: relu6(v * scale[n] + shift[n]), scale passed as `bias`, shift as `shift`
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
 __host__ __device__ constexpr int stride16(int c) { return (c % 32 == 16) ? c : c + 16; }   // == 16 (mod 32)
@@ -210,7 +211,7 @@ struct Bf16Planes { const __bf16 *p[3]; };
 template <int CR, int CO, int MODE, int EPI, int RT, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restrict__ src, Bf16Planes wp, const float *__restrict__ bias,
                                                          float *__restrict__ dst, ConvGeom g, double *__restrict__ partial = nullptr,
-                                                         int partial_stride = 0)
+                                                         int partial_stride = 0, const float *__restrict__ shift = nullptr)
 {
     constexpr int KC = 32, SK = 40;            // chunk depth and LDS row stride in bf16 units
     constexpr int BM = 32 * RT;                // rows per block: RT row tiles per wave, 2 waves along M
@@ -336,9 +337,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int n = 16 * (wn * CT + c) + li;
-        float bv = 0.f;
+        float bv = 0.f, sv = 0.f;
         ssum[c] = 0.f; ssq[c] = 0.f;
-        if (EPI == EPI_BIAS_RELU6 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bv = bias[n];
+        if (EPI == EPI_BIAS_RELU6 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BN_RELU6) bv = bias[n];
+        if (EPI == EPI_BN_RELU6) sv = shift[n];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
                     if (EPI == EPI_BIAS_RELU6) v = relu6f(v + bv);
                     if (EPI == EPI_BIAS) v = v + bv;
                     if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
+                    if (EPI == EPI_BN_RELU6) v = relu6f(fmaf(v, bv, sv));
                     dst[m * CO + n] = v;
                     if (STATS) { ssum[c] += v; ssq[c] = fmaf(v, v, ssq[c]); }
                 }
@@ -695,16 +698,26 @@ __global__ __launch_bounds__(256) void conv_dgrad_direct_kernel(const float *__r
 // fragments stay in registers.  The BatchNormalization batch statistics are fused: every lane accumulates sum / sum of
 // squares of its output column and the block writes ONE double partial per channel (the layout bn_finalize_train_kernel
 // reads), so the pre-BN tensor is not re-read by a statistics pass.
-template <int COUT, bool STATS>
+// POOLED (inference): the tiles enumerate 2x2 pool windows (pixel p = 4*window + element, as in kws_layer1.h), so a lane's
+// four accumulator rows are one window; the epilogue applies the BatchNorm affine, ReLU6 and the max and writes the pooled
+// activation (H/2 x W/2 x COUT) instead of the conv output: no z-sized tensor, no separate activation pass.
+template <int COUT, bool STATS, bool POOLED = false>
 __global__ __launch_bounds__(256) void conv_fwd_clip_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
                                                              float *__restrict__ z, int B, int H, int W,
-                                                             double *__restrict__ partial, int partial_stride)
+                                                             double *__restrict__ partial, int partial_stride,
+                                                             const float *__restrict__ scale = nullptr,
+                                                             const float *__restrict__ shift = nullptr)
 {
     constexpr int CIN = 16, NT = COUT / 16, XP = CIN + 4;          // padded pixel stride (words)
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [(H+2)][(W+2)][XP], zero halo
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lq = lane >> 4;
-    const int HP = H + 2, WP = W + 2, HW = H * W, ntile = (HW + 15) / 16;
+    const int HP = H + 2, WP = W + 2, HW = H * W;
+    const int W2 = W / 2, n2 = (H / 2) * W2;                       // pool windows (POOLED)
+    const int ntile = POOLED ? (n2 + 3) / 4 : (HW + 15) / 16;
     for (int i = threadIdx.x; i < HP * WP * XP; i += 256) tile[i] = 0.f;
+    float sc[NT], sh[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { sc[nt] = POOLED ? scale[16 * nt + li] : 1.f; sh[nt] = POOLED ? shift[16 * nt + li] : 0.f; }
 
     // B fragments: k-step j of tap t multiplies input channel 4 lq + j; lane holds W[t][4 lq + j][16 nt + li]
     float wf[9][4][NT];
@@ -748,8 +761,16 @@ __global__ __launch_bounds__(256) void conv_fwd_clip_kernel(const float *__restr
         __syncthreads();
         if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
         for (int t = wave; t < ntile; t += 4) {
-            const int p = 16 * t + li, pc = p < HW ? p : HW - 1;
-            const int oh = pc / W, ow = pc % W;
+            int oh, ow;
+            if (POOLED) {                                            // A row li = element li & 3 of window 4 t + (li >> 2)
+                int wq = 4 * t + (li >> 2);
+                wq = wq < n2 ? wq : 0;
+                oh = 2 * (wq / W2) + ((li & 3) >> 1);
+                ow = 2 * (wq % W2) + (li & 1);
+            } else {
+                const int p = 16 * t + li, pc = p < HW ? p : HW - 1;
+                oh = pc / W; ow = pc % W;
+            }
             const float *a0 = &tile[(oh * WP + ow) * XP + 4 * lq];  // tap (0,0) of this pixel in halo coordinates
             f32x4 acc[NT];
 #pragma unroll
@@ -769,6 +790,18 @@ __global__ __launch_bounds__(256) void conv_fwd_clip_kernel(const float *__restr
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(a.w, wf[tp][3][nt], acc[nt]);
                 }
+            if (POOLED) {
+                const int wd = 4 * t + lq;                          // this lane's four rows are the elements of window wd
+                if (wd < n2) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const float m = fmaxf(fmaxf(fmaf(acc[nt][0], sc[nt], sh[nt]), fmaf(acc[nt][1], sc[nt], sh[nt])),
+                                              fmaxf(fmaf(acc[nt][2], sc[nt], sh[nt]), fmaf(acc[nt][3], sc[nt], sh[nt])));
+                        z[((long)b * n2 + wd) * COUT + 16 * nt + li] = relu6f(m);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int po = 16 * t + 4 * lq + r;

@@ -205,7 +205,7 @@ static int g_matrix_precision = 1;
 // returns the number of blocks that wrote BatchNorm partial sums (0: `partial` was not given or the grid exceeds its stride)
 template <int CR, int CO, int MODE, int EPI>
 int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], const float *bias, float *dst, const ConvGeom &g,
-                hipStream_t s, double *partial = nullptr)
+                hipStream_t s, double *partial = nullptr, const float *shift = nullptr)
 {
     const long M = MODE == MODE_FWD ? (long)g.B * g.Ho * g.Wo : (long)g.B * g.H * g.W;
     static const std::string name = std::string(what) + "<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
@@ -220,7 +220,7 @@ int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], con
                    kStatStride);
         return (int)nblk;
     }
-    KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, false>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, nullptr, 0);
+    KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, false>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, nullptr, 0, shift);
     return 0;
 }
 
@@ -310,9 +310,17 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                            w.partial, kStatStride);
                 fused_stat_blocks = (int)nblk;
             } else {
-                KWS_LAUNCH("conv_fwd_clip<16,32>", (conv_fwd_clip_kernel<32, false>), dim3(nblk), dim3(256), sm, s, in, kern, w.z[1], B, Hs[1], Ws[1],
-                           w.partial, kStatStride);
+                // inference: BatchNorm affine + ReLU6 + 2x2 max in the kernel's epilogue, a2 written directly
+                const BnCoef k2 = coef_of(w.coef[1], 32);
+                KWS_LAUNCH("conv_fwd_clip_pool<16,32>", (conv_fwd_clip_kernel<32, false, true>), dim3(nblk), dim3(256), sm, s, in, kern, w.a[1], B,
+                           Hs[1], Ws[1], w.partial, kStatStride, k2.scale, k2.shift);
+                continue;
             }
+        } else if (l == 2 && bf16 && !training) {
+            // inference: BatchNorm affine + ReLU6 in the epilogue, a3 written directly (conv3 has no pool)
+            const BnCoef k3 = coef_of(w.coef[2], 64);
+            launch_bf16<32, 64, MODE_FWD, EPI_BN_RELU6>("conv_bf16_fwd_bn", in, w.wsp[0], k3.scale, w.a[2], geom3x3(B, Hs[2], Ws[2], 2), s, nullptr, k3.shift);
+            continue;
         } else if (l == 2) {
             if (bf16 && training) KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(11), 0));     // the weight planes are ready
             // the split-precision kernels write the BatchNorm partial sums from their epilogue when training

@@ -37,6 +37,7 @@ struct FeatDev {
     int window_eff, hop, max_samples, n_frames, n_filt, n_out, feature_size, use_delta, nchunks, nnz;
     int chp, n_filt_pad;   // chunk length padded to a multiple of 4 (zero weights); n_filt rounded up to 4 (zero DCT rows)
     int tail_batch;        // frames whose band sums / DCT one wave evaluates together (lanes = frames x bands)
+    int fpw, jpc;          // frames per wave job, jobs per clip (set per launch: launch_featurize)
     float inv_nfft;
     const float2 *tw1;   // [7][64]  W_512^(lane*k1), k1 = 1..7
     const float2 *tw2;   // [7][8]   W_64^(l2*k2a),   k2a = 1..7
@@ -166,8 +167,12 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is uniform: telling the compiler so keeps the frame loop, its counters and branches in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
-    if (b >= B) return;
+    // A wave owns one JOB = c.fpw consecutive frames of one clip.  Without deltas the jobs of all clips are dealt to the
+    // waves in order (job = blockIdx.x * kWaves + wave), so short clips -- a streaming step featurizes 2 frames per stream --
+    // still fill every wave; at the default geometry (30 frames, 6 per job, 5 jobs per clip) this is block = clip.  With
+    // deltas the block keeps one clip (its coefficients are staged in s_feat for the frame differences).
+    const int job = c.use_delta ? (wave < c.jpc ? (int)blockIdx.x * c.jpc + wave : -1) : (int)blockIdx.x * kWaves + wave;
+    const int b = job < 0 ? B : job / c.jpc;
 
     const int tb = c.tail_batch;
     float2 *s_fft = reinterpret_cast<float2 *>(smem) + wave * kFftTile;
@@ -191,12 +196,13 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
     __syncthreads();
 
     // clip geometry: keep the head, left-pad zeros (data_utils.py:77-80)
-    int len = valid_len ? valid_len[b] : (stride > c.max_samples ? c.max_samples : (int)stride);
+    const int bc = b < B ? b : 0;                                          // idle waves (no job) read clip 0's geometry and do nothing
+    int len = valid_len ? valid_len[bc] : (stride > c.max_samples ? c.max_samples : (int)stride);
     len = len < 0 ? 0 : len;
     if ((int64_t)len > stride) len = (int)stride;
     if (len > c.max_samples) len = c.max_samples;
     const int pad = c.max_samples - len;
-    const WavT *src = wav + (int64_t)b * stride;
+    const WavT *src = wav + (int64_t)bc * stride;
     const bool vec_ok = (((pad | c.hop | c.window_eff) & 1) == 0) &&
                         ((reinterpret_cast<uintptr_t>(src) & (2 * sizeof(WavT) - 1)) == 0);
     const bool reuse = 2 * c.hop == 1024 && c.window_eff == 1024;          // frame f+1 starts with frame f's upper half
@@ -205,10 +211,10 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
     // per-lane roles in the batched tail
     const int chunk_first = lane < c.nchunks ? c.chunks[lane].y : 0;       // gather: lane = one chunk of one band
     const float r_filt = 1.0f / (float)c.n_filt, r_out = 1.0f / (float)c.n_out;
-    float *dst = feat + (int64_t)b * c.n_frames * c.feature_size;
+    float *dst = feat + (int64_t)bc * c.n_frames * c.feature_size;
 
-    const int fpw = (c.n_frames + kWaves - 1) / kWaves;
-    const int f_beg = wave * fpw, f_end = f_beg + fpw < c.n_frames ? f_beg + fpw : c.n_frames;
+    const int f_beg = b < B ? (job - b * c.jpc) * c.fpw : c.n_frames;
+    const int f_end = f_beg + c.fpw < c.n_frames ? f_beg + c.fpw : c.n_frames;
 
     float2 xl[4], xh[4];                // lower / upper half of the next frame to transform
     if (f_beg < f_end) {
@@ -382,6 +388,7 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
     }
     if (!c.use_delta) return;
     __syncthreads();
+    dst = feat + (int64_t)blockIdx.x * c.n_frames * c.feature_size;        // with deltas the block is one clip
 
     // add_deltas (data_utils.py:50-58): the clip's (n_features x 2 n_out) block from the staged coefficients
     const int total = c.n_frames * c.feature_size;
@@ -776,14 +783,22 @@ static int launch_generic(const FeatDev &d, const void *wav, int wav_dtype, int 
     return KWS_OK;
 }
 
-static int launch_featurize(const FeatDev &d, const void *wav, int wav_dtype, int B, int64_t stride,
+static int launch_featurize(const FeatDev &d0, const void *wav, int wav_dtype, int B, int64_t stride,
                             const int32_t *valid_len, float *feat, void *stream)
 {
-    if (d.n_fft != 1024) return launch_generic(d, wav, wav_dtype, B, stride, valid_len, feat, stream);
+    if (d0.n_fft != 1024) return launch_generic(d0, wav, wav_dtype, B, stride, valid_len, feat, stream);
+    FeatDev d = d0;
+    // wave jobs: fpw consecutive frames of one clip.  Long clips: an equal share per wave of a block; short ones (a
+    // streaming step has 2 frames per stream): a whole tail batch per job so that one wave serves a stream
+    d.fpw = (d.n_frames + kWaves - 1) / kWaves;
+    if (!d.use_delta) d.fpw = std::max(d.fpw, std::min(d.n_frames, d.tail_batch));
+    d.fpw = std::max(1, d.fpw);
+    d.jpc = std::max(1, (d.n_frames + d.fpw - 1) / d.fpw);
     const size_t smem = feat_smem_bytes(d);
     if (smem > 160 * 1024) return fail(KWS_ERR_UNSUPPORTED, "%d frames need %zu B of LDS (> 160 KiB)", d.n_frames, smem);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)B), block(kThreads);
+    const long jobs = (long)B * d.jpc;
+    const dim3 grid((unsigned)(d.use_delta ? B : (jobs + kWaves - 1) / kWaves)), block(kThreads);
     if (wav_dtype == KWS_WAV_F32) {
         if (smem > 64 * 1024)
             KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_fft1024_kernel<float>),

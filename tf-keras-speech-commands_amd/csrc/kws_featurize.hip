@@ -18,6 +18,8 @@
 #include <cstring>
 #include <vector>
 
+#include <functional>
+
 #include "kws_common.h"
 #include "kws_device.h"
 
@@ -42,9 +44,9 @@ struct FeatDev {
     const float2 *tw1;   // [7][64]  W_512^(lane*k1), k1 = 1..7
     const float2 *tw2;   // [7][8]   W_64^(l2*k2a),   k2a = 1..7
     const float2 *tws;   // [257]    W_1024^k
-    const int4 *chunks;  // [nchunks] {band, first bin, count, offset into w}
+    const int4 *chunks;  // [64 lanes] {band, first bin read, chunk id, 0}: lane placement is bank-conflict free (host matching)
     const int *bcs;      // [n_filt+1] first chunk of each band
-    const float *w;      // [nchunks][chp] bank weights, zero padded (nnz = nchunks*chp)
+    const float *w;      // [64 lanes][chp] bank weights of the lane's window, zero outside its chunk (nnz = 64*chp)
     const float *dct;    // [n_filt_pad][n_out], ortho scaling folded in, zero rows past n_filt
     // generic path (n_fft != 1024): radix-2 twiddles and the bank as per-band spans
     int n_fft, log2n;
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
 
     const int hi = lane >> 3, lo = lane & 7;
     // per-lane roles in the batched tail
-    const int chunk_first = lane < c.nchunks ? c.chunks[lane].y : 0;       // gather: lane = one chunk of one band
+    // gather: lane = one chunk of one band; its first bin and its chunk id (the slot of its partial sum) packed in one register
+    const int chunk_pack = c.chunks[lane].y | (c.chunks[lane].z << 16);
     const float r_filt = 1.0f / (float)c.n_filt, r_out = 1.0f / (float)c.n_out;
     float *dst = feat + (int64_t)bc * c.n_frames * c.feature_size;
 
@@ -317,8 +320,8 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
         continue;
 #endif
         float part = 0.f;
-        if (lane < c.nchunks) {
-            const float *pp = s_pw + chunk_first;
+        {
+            const float *pp = s_pw + (chunk_pack & 0xFFFF);
             const float *wp = s_w + lane * c.chp;
             for (int t = 0; t < c.chp; t += 4) {
                 const float4 wv = *reinterpret_cast<const float4 *>(wp + t);
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
                 part = fmaf(p3, wv.w, part);
             }
         }
-        s_part[qi * 64 + lane] = part;
+        s_part[qi * 64 + (chunk_pack >> 16)] = part;
         if (lane == 0) s_en[qi] = energy;
         ++qi;
         if (qi < tb && f + 1 < f_end) continue;
@@ -626,18 +629,67 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
         if (cnt <= kMaxChunks) break;
     }
     const int chp = (ch + 3) & ~3, n_filt_pad = (n_filt + 3) & ~3;
-    std::vector<int4> chunks;
+    // logical chunks in band order: (band, first bin, bins)
+    struct Chunk { int band, a, len; };
+    std::vector<Chunk> logical;
     std::vector<int> bcs(n_filt + 1, 0);
-    std::vector<float> w;
     for (int i = 0; i < n_filt; ++i) {
-        bcs[i] = (int)chunks.size();
-        for (int off = 0; off < width[i]; off += ch) {
-            const int cnt = std::min(ch, width[i] - off);
-            chunks.push_back(make_int4(i, first[i] + off, cnt, (int)w.size()));
-            for (int t = 0; t < chp; ++t) w.push_back(t < cnt ? (float)bank[(size_t)i * n_bins + first[i] + off + t] : 0.f);
+        bcs[i] = (int)logical.size();
+        for (int off = 0; off < width[i]; off += ch) logical.push_back(Chunk{i, first[i] + off, std::min(ch, width[i] - off)});
+    }
+    bcs[n_filt] = (int)logical.size();
+    const int nlog = (int)logical.size();
+    // Lane placement.  Every lane reads p[start + t] for the same t, so the 32 lanes of a half-wave hit 32 different LDS
+    // banks iff their starts differ mod 32.  A chunk of `len` bins may start anywhere in [a + len - chp, a] (the extra bins
+    // get zero weights), so: bipartite matching of chunks to the 64 (half, residue) slots, lane = 32 * half + residue.
+    // (Chunk starts taken as they come collide ~3-way on average: 29 % of the kernel's LDS cycles were conflicts.)
+    std::vector<int> slot_of(nlog, -1), start_of(nlog, 0), owner(64, -1);
+    {
+        std::vector<std::vector<std::pair<int, int>>> cand(nlog);          // (slot, start)
+        for (int c = 0; c < nlog; ++c)
+            for (int st = logical[c].a; st >= std::max(0, logical[c].a + logical[c].len - chp); --st)
+                for (int h = 0; h < 2; ++h) cand[c].push_back({32 * h + (st & 31), st});
+        std::vector<int> owner_start(64, 0);
+        std::function<bool(int, std::vector<char> &)> place = [&](int c, std::vector<char> &seen) -> bool {
+            for (auto &e : cand[c]) {
+                if (seen[e.first]) continue;
+                seen[e.first] = 1;
+                if (owner[e.first] < 0 || place(owner[e.first], seen)) {
+                    owner[e.first] = c; owner_start[e.first] = e.second;
+                    return true;
+                }
+            }
+            return false;
+        };
+        bool perfect = true;
+        for (int c = 0; c < nlog && perfect; ++c) {
+            std::vector<char> seen(64, 0);
+            perfect = place(c, seen);
+        }
+        if (perfect) {
+            for (int sl = 0; sl < 64; ++sl)
+                if (owner[sl] >= 0) { slot_of[owner[sl]] = sl; start_of[owner[sl]] = owner_start[sl]; }
+        } else {                                                           // keep the natural order (correct, just slower)
+            std::fill(owner.begin(), owner.end(), -1);
+            for (int c = 0; c < nlog; ++c) { slot_of[c] = c; start_of[c] = logical[c].a; owner[c] = c; }
         }
     }
-    bcs[n_filt] = (int)chunks.size();
+    // per-lane tables (always 64 lanes): {band, start, chunk id, 0} and chp weights; idle lanes take the unused chunk ids
+    std::vector<int4> chunks(64);
+    std::vector<float> w((size_t)64 * chp, 0.f);
+    {
+        int spare = nlog;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int c = owner[lane];
+            if (c < 0) { chunks[lane] = make_int4(0, 0, spare < 64 ? spare++ : 63, 0); continue; }
+            chunks[lane] = make_int4(logical[c].band, start_of[c], c, 0);
+            for (int t = 0; t < chp; ++t) {
+                const int bin = start_of[c] + t;
+                if (bin >= logical[c].a && bin < logical[c].a + logical[c].len)
+                    w[(size_t)lane * chp + t] = (float)bank[(size_t)logical[c].band * n_bins + bin];
+            }
+        }
+    }
 
     std::vector<float2> tw1(7 * 64), tw2(7 * 8), tws(257);
     for (int k = 1; k < 8; ++k)
@@ -708,7 +760,7 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     d.window_eff = std::min(g.window_samples, (int)p->n_fft);  // np.fft.rfft(frames, n): crop or zero-pad (bark_feature.py:87)
     d.hop = g.hop_samples; d.max_samples = g.max_samples; d.n_frames = n_frames;
     d.n_filt = n_filt; d.n_out = n_out; d.feature_size = g.feature_size; d.use_delta = p->use_delta ? 1 : 0;
-    d.nchunks = (int)chunks.size(); d.nnz = (int)w.size(); d.inv_nfft = 1.0f / (float)p->n_fft;
+    d.nchunks = nlog; d.nnz = (int)w.size(); d.inv_nfft = 1.0f / (float)p->n_fft;
     d.chp = chp; d.n_filt_pad = n_filt_pad;
     d.tail_batch = std::max(1, std::min(4, 64 / std::max(n_filt_pad, n_out)));
     d.tw1 = reinterpret_cast<const float2 *>(base + o_tw1);

@@ -493,3 +493,43 @@ def test_bucket_event_marks_final_early_gradients(torch):
         torch.cuda.synchronize()
         assert torch.equal(snap, dm.grads[split:]), it     # nothing in the early bucket changed afterwards
         assert float(snap.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("model_type,nf,fs", [("simple_cnn", 29, 13), ("simple_cnn", 40, 24), ("simple_cnn", 24, 16), ("simple_cnn", 62, 21),
+                                              ("simple_cnn_lite", 29, 13), ("simple_cnn_lite", 40, 24),
+                                              ("simple_gru", 17, 13), ("simple_lstm", 23, 40)])
+def test_other_geometries_train_and_infer(torch, model_type, nf, fs):
+    """Feature maps other than the default 30 x 20 (other window / hop / n_mfcc settings in params.json): odd sizes take
+    the per-thread layer-1 kernels and leave pixels outside the pool windows, larger ones exceed the wave-per-clip tile
+    limits, other widths change every clip-kernel and parity-class grid."""
+    from kws_amd.model import DeviceModel, ModelSpec
+    from oracle import model_oracle as mo
+    C, B = 6, 21
+    om = mo.Model(model_type, C, n_features=nf, feature_size=fs).init_weights(nf + fs)
+    rng = np.random.default_rng(nf * 100 + fs)
+    ws = om.get_weights()
+    for i, (li, n, t) in enumerate(om.weight_list()):
+        if n in ("gamma", "moving_variance"):
+            ws[i] = ws[i] * rng.uniform(0.5, 1.5, ws[i].shape)
+        elif n in ("beta", "bias", "moving_mean"):
+            ws[i] = ws[i] + 0.1 * rng.standard_normal(ws[i].shape)
+    om.set_weights(ws)
+    dm = DeviceModel(ModelSpec(model_type, C, nf, fs))
+    dm.set_weights(om.get_weights())
+    x = (rng.standard_normal((B, nf, fs)) * 2.0).astype(np.float32)
+    y = rng.integers(0, C, B)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
+    want = om.predict(x.astype(np.float64))
+    probs, am = dm.forward(xt)
+    np.testing.assert_allclose(probs.cpu().numpy(), want, atol=1e-4, rtol=0)
+    np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
+    seed = 4242 + nf
+    loss, acc, p = mo.train_forward_backward(om, x.astype(np.float64), y, dropout_seed=seed)
+    pt = dm.train_fwd_bwd(xt, yt, dropout_seed=seed, want_probs=True)
+    np.testing.assert_allclose(pt.cpu().numpy(), p, atol=1e-4, rtol=0)
+    assert abs(float(dm.stats[0].item()) / B - loss) < 1e-4
+    for g, w, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
+        # the pointwise bias in front of a BatchNormalization has an analytically zero gradient (1e-17 in the float64
+        # oracle): the float32 path leaves rounding noise of its summed terms there, hence an absolute floor for the lite model
+        floor = 3e-5 if model_type == "simple_cnn_lite" else 0.0
+        assert np.abs(g - w).max() <= 3e-4 * np.abs(w).max() + floor, (li, n, rel_err(g, w))

@@ -362,6 +362,78 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__
     }
 }
 
+// Fast form for heads whose W2 (K x C) fits in LDS next to the 16-sample tile: W2 is staged once per block (the kernel above
+// reads it from global memory inside the K loop), and a sample's classes are spread over 16 lanes, so the arg-max, the
+// softmax sums and the writes are 16-wide instead of one thread per sample.  Same arithmetic order per logit (k ascending),
+// same first-maximum rule, same loss formulas.
+__global__ __launch_bounds__(256) void head_fwd_fast_kernel(const float *__restrict__ d1, const float *__restrict__ w2,
+                                                             const float *__restrict__ b2, const int32_t *__restrict__ labels,
+                                                             const float *__restrict__ class_w, float *__restrict__ probs,
+                                                             int32_t *__restrict__ argmax_out, float *__restrict__ loss_i,
+                                                             float *__restrict__ correct_i, float *__restrict__ dlogits, int B,
+                                                             int K, int C, float grad_scale, int ignore_index)
+{
+    extern __shared__ float hs[];
+    const int KS = K + 1;        // padded row: the 16 samples of a column read different banks
+    float *xs = hs;              // [16][KS]
+    float *ws = hs + 16 * KS;    // [K][C]
+    float *lg = ws + K * C;      // [16][C]
+    const int b0 = blockIdx.x * 16;
+    for (int i = threadIdx.x; i < 16 * K; i += 256) {
+        const int s = i / K, k = i - s * K;
+        xs[s * KS + k] = (b0 + s < B) ? d1[(long)(b0 + s) * K + k] : 0.f;
+    }
+    for (int i = threadIdx.x; i < K * C; i += 256) ws[i] = w2[i];
+    __syncthreads();
+    const int s = threadIdx.x >> 4, j = threadIdx.x & 15, b = b0 + s;
+    // logits of classes j, j + 16, ...
+    for (int c = j; c < C; c += 16) {
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc = fmaf(xs[s * KS + k], ws[k * C + c], acc);
+        lg[s * C + c] = acc + b2[c];
+    }
+    __syncthreads();
+    // first maximum over the sample's classes: per lane over its classes (ascending), then across the 16 lanes (lower class wins ties)
+    float mx = -INFINITY;
+    int am = 0x7fffffff;
+    for (int c = j; c < C; c += 16) {
+        const float v = lg[s * C + c];
+        if (v > mx) { mx = v; am = c; }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const float omx = __shfl_xor(mx, o, 16);
+        const int oam = __shfl_xor(am, o, 16);
+        if (omx > mx || (omx == mx && oam < am)) { mx = omx; am = oam; }
+    }
+    float sum = 0.f;
+    for (int c = j; c < C; c += 16) { const float e = expf(lg[s * C + c] - mx); lg[s * C + c] = e; sum += e; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+    const float rs = 1.f / sum;
+    if (b >= B) return;
+    if (argmax_out && j == 0) argmax_out[b] = am;
+    if (probs)
+        for (int c = j; c < C; c += 16) probs[(long)b * C + c] = lg[s * C + c] * rs;
+    if (labels) {
+        const int y = labels[b];
+        const float py = lg[s * C + y] * rs;      // written by lane y % 16 before the shuffles above (same wave: in order)
+        float loss, coef;
+        if (class_w) {                       // loss.py:67-71: -log(p_y) * w_y, no clipping
+            loss = -logf(py) * class_w[y];
+            coef = class_w[y];
+        } else {                             // loss.py:36: K.categorical_crossentropy on probabilities (clipped)
+            const float lo = kCeEps, hi = 1.f - kCeEps;
+            loss = -logf(fminf(fmaxf(py, lo), hi));
+            coef = (py >= lo && py <= hi) ? 1.f : 0.f;
+        }
+        if (ignore_index > 0 && y == ignore_index) { loss = 0.f; coef = 0.f; }   // loss.py:38-40,73-75
+        if (j == 0) { loss_i[b] = loss; correct_i[b] = am == y ? 1.f : 0.f; }
+        if (dlogits)
+            for (int c = j; c < C; c += 16) dlogits[(long)b * C + c] = (lg[s * C + c] * rs - (c == y ? 1.f : 0.f)) * coef * grad_scale;
+    }
+}
+
 // deterministic sum of per-sample losses / correct flags: out[0] = sum(loss), out[1] = sum(correct)
 __global__ __launch_bounds__(256) void loss_reduce_kernel(const float *__restrict__ loss_i, const float *__restrict__ correct_i,
                                                            int B, float *__restrict__ out)
@@ -414,6 +486,86 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
         for (int s = 0; s < kHeadBwdRows; ++s) acc += ds[s * C + c];
         atomicAdd(db2 + c, acc);
     }
+}
+
+// Fast form of the head backward for K a multiple of 16 and C <= 48 (W2 and the tiles fit in LDS): the two small products
+// run on the fp32 MFMA.  Block = 16 samples, 4 waves.
+//   dW2[k][c] += sum_r x[r][k] dl[r][c]      M = K (K/16 tiles), N = 48 (3 tiles), reduction over the 16 samples (4 k-steps)
+//   dx[r][k]   = sum_c dl[r][c] W2[k][c]      M = 16 samples, N = K (K/16 tiles), reduction over 48 padded classes (12 k-steps)
+// dl and W2 are zero-padded to 48 columns in LDS, so no lane needs a mask; dW2 / db2 are added with float atomics as before.
+template <bool RELU6_GATE, int GROUPS>
+__global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w2,
+                                                             const float *__restrict__ dlogits, float *__restrict__ dx,
+                                                             float *__restrict__ dw2, float *__restrict__ db2, int B, int K, int C)
+{
+    // GROUPS 16-sample groups per block: dW2 / db2 accumulate in registers across them, so the float atomics (one per
+    // entry and block -- the kernel's bound) shrink by that factor.  K <= 128 (at most 6 dW2 tiles per wave).
+    constexpr int CP = 48, CS = 50;                 // padded classes; LDS row stride (== 18 mod 32: conflict-free column reads)
+    constexpr int MAXT = 6;
+    extern __shared__ float hs[];
+    const int KS = K + 2;                           // x tile row stride
+    float *xs = hs;                                 // [16][KS]
+    float *ds = xs + 16 * KS;                       // [16][CS], columns >= C are zero
+    float *ws = ds + 16 * CS;                       // [K][CS],  columns >= C are zero
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    const int KT = K / 16;
+    for (int i = threadIdx.x; i < K * CP; i += 256) { const int k = i / CP, c = i - k * CP; ws[k * CS + c] = c < C ? w2[(long)k * C + c] : 0.f; }
+    f32x4 accw[MAXT];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) accw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    for (int gi = 0; gi < GROUPS; ++gi) {
+        const int b0 = (blockIdx.x * GROUPS + gi) * 16;
+        if (b0 >= B) break;
+        __syncthreads();                            // the previous group's reads of xs / ds are done
+        for (int i = threadIdx.x; i < 16 * K; i += 256) { const int r = i / K, k = i - r * K; xs[r * KS + k] = (b0 + r < B) ? x[(long)(b0 + r) * K + k] : 0.f; }
+        for (int i = threadIdx.x; i < 16 * CP; i += 256) { const int r = i / CP, c = i - r * CP; ds[r * CS + c] = (c < C && b0 + r < B) ? dlogits[(long)(b0 + r) * C + c] : 0.f; }
+        __syncthreads();
+        // dx tiles: one per 16 input features, dealt to the waves
+        for (int nt = wave; nt < KT; nt += 4) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < CP / 4; ++j) acc = mfma16(ds[li * CS + 4 * j + lq], ws[(16 * nt + li) * CS + 4 * j + lq], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * lq + r, k = 16 * nt + li;
+                if (b0 + row < B) {
+                    float v = acc[r];
+                    if (RELU6_GATE) { const float xv = xs[row * KS + k]; v = (xv > 0.f && xv < 6.f) ? v : 0.f; }
+                    dx[(long)(b0 + row) * K + k] = v;
+                }
+            }
+        }
+        // dW2 tiles: (K/16) x 3, dealt to the waves, accumulated over the groups
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q) {
+            const int t = wave + 4 * q;
+            if (t < KT * 3) {
+                const int mt = t / 3, nt = t - 3 * mt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accw[q] = mfma16(xs[(4 * j + lq) * KS + 16 * mt + li], ds[(4 * j + lq) * CS + 16 * nt + li], accw[q]);
+            }
+        }
+        if ((int)threadIdx.x < C)
+            for (int r = 0; r < 16; ++r) accb += ds[r * CS + threadIdx.x];
+    }
+    // gather the dense (K x C) block in LDS so that the float atomics of a wave-instruction hit 64 contiguous addresses
+    // (strided float atomics run ~10x slower)
+    __syncthreads();                                // everyone is done with ws: reuse it as dW2[K][C]
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        const int t = wave + 4 * q;
+        if (t < KT * 3) {
+            const int mt = t / 3, nt = t - 3 * mt, c = 16 * nt + li;
+            if (c < C) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ws[(16 * mt + 4 * lq + r) * C + c] = accw[q][r];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * C; i += 256) atomicAdd(dw2 + i, ws[i]);
+    if ((int)threadIdx.x < C) atomicAdd(db2 + threadIdx.x, accb);
 }
 
 // per-column sums of an (M x C) matrix into out[C] (bias gradients); reuses the double partial slab

@@ -662,6 +662,11 @@ int run_head(const kws_model *m, int B, const float *params, const float *x, flo
 {
     const int K = m->head_K;
     const size_t smem = sizeof(float) * (size_t)(16 * K + 16 * m->C);
+    const size_t smem_fast = sizeof(float) * (size_t)(16 * (K + 1) + K * m->C + 16 * m->C);
+    if (smem_fast <= 60 * 1024)      // W2 fits in LDS beside the tile (C <= ~100 at K = 128): the 16-lanes-per-sample form
+        KWS_LAUNCH("head_fwd_kernel", head_fwd_fast_kernel, dim3(blocks_for(B, 16)), dim3(256), smem_fast, s, x, params + m->o_hk, params + m->o_hb,
+                   labels, class_w, probs, argmax, loss_i, correct_i, dlogits, B, K, m->C, grad_scale, ignore_index);
+    else
     KWS_LAUNCH("head_fwd_kernel", head_fwd_kernel, dim3(blocks_for(B, 16)), dim3(256), smem, s, x, params + m->o_hk, params + m->o_hb,
                labels, class_w, probs, argmax, loss_i, correct_i, dlogits, B, K, m->C, grad_scale, ignore_index);
     if (labels && stats) KWS_LAUNCH("loss_reduce_kernel", loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_i, correct_i, B, stats);
@@ -674,6 +679,18 @@ int run_head_bwd(const kws_model *m, int B, const float *params, const float *x,
 {
     const int K = m->head_K;
     const size_t smem = sizeof(float) * (size_t)(kHeadBwdRows * K + kHeadBwdRows * m->C);
+    if (K % 16 == 0 && K <= 128 && m->C <= 48) {    // the MFMA form: W2, a 16-sample tile and dlogits padded to 48 classes live in LDS
+        constexpr int G = 1;                          // 16-sample groups per block (4 measured slower: 64 blocks expose each group's staging latency)
+        const size_t smem_fast = sizeof(float) * (size_t)(16 * (K + 2) + (16 + K) * 50);
+        if (relu6_gate)
+            KWS_LAUNCH("head_bwd_kernel", (head_bwd_mfma_kernel<true, G>), dim3(blocks_for(B, 16 * G)), dim3(256), smem_fast, s, x, params + m->o_hk, dlogits,
+                       dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
+        else
+            KWS_LAUNCH("head_bwd_kernel", (head_bwd_mfma_kernel<false, G>), dim3(blocks_for(B, 16 * G)), dim3(256), smem_fast, s, x, params + m->o_hk, dlogits,
+                       dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
+        KWS_LAUNCH_CHECK("head backward");
+        return KWS_OK;
+    }
     if (relu6_gate)
         KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<true>, dim3(blocks_for(B, kHeadBwdRows)), dim3(256), smem, s, x, params + m->o_hk, dlogits,
                    dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);

@@ -496,8 +496,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
 template <bool RELU6_GATE, int GROUPS>
 __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w2,
                                                              const float *__restrict__ dlogits, float *__restrict__ dx,
-                                                             float *__restrict__ dw2, float *__restrict__ db2, int B, int K, int C)
+                                                             float *__restrict__ dw2, float *__restrict__ db2, int B, int K, int C,
+                                                             float *__restrict__ dx_colsum, const float *__restrict__ loss_i,
+                                                             const float *__restrict__ correct_i, float *__restrict__ stats)
 {
+    // dx_colsum (nullable): += column sums of dx, i.e. the bias gradient of the layer that produced x (float atomics).
+    // stats (nullable): block 0 also writes {sum of loss_i, sum of correct_i} in a fixed order (double), which saves the
+    // separate loss_reduce launch of a train step.
     // GROUPS 16-sample groups per block: dW2 / db2 accumulate in registers across them, so the float atomics (one per
     // entry and block -- the kernel's bound) shrink by that factor.  K <= 128 (at most 6 dW2 tiles per wave).
     constexpr int CP = 48, CS = 50;                 // padded classes; LDS row stride (== 18 mod 32: conflict-free column reads)
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restr
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < CP / 4; ++j) acc = mfma16(ds[li * CS + 4 * j + lq], ws[(16 * nt + li) * CS + 4 * j + lq], acc);
+            float cs = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * lq + r, k = 16 * nt + li;
@@ -533,7 +539,13 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restr
                     float v = acc[r];
                     if (RELU6_GATE) { const float xv = xs[row * KS + k]; v = (xv > 0.f && xv < 6.f) ? v : 0.f; }
                     dx[(long)(b0 + row) * K + k] = v;
+                    cs += v;
                 }
+            }
+            if (dx_colsum) {                        // lanes with equal li hold the same column: reduce over lq, one atomic per column
+                cs += __shfl_xor(cs, 16, 64);
+                cs += __shfl_xor(cs, 32, 64);
+                if (lq == 0) atomicAdd(dx_colsum + 16 * nt + li, cs);
             }
         }
         // dW2 tiles: (K/16) x 3, dealt to the waves, accumulated over the groups
@@ -566,6 +578,19 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restr
     __syncthreads();
     for (int i = threadIdx.x; i < K * C; i += 256) atomicAdd(dw2 + i, ws[i]);
     if ((int)threadIdx.x < C) atomicAdd(db2 + threadIdx.x, accb);
+    if (stats && blockIdx.x == 0) {                 // deterministic: fixed strided partition, tree in double
+        double sl = 0.0, sc = 0.0;
+        for (int i = threadIdx.x; i < B; i += 256) { sl += (double)loss_i[i]; sc += (double)correct_i[i]; }
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(hs);
+        red[threadIdx.x] = sl; red[256 + threadIdx.x] = sc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; red[256 + threadIdx.x] += red[256 + threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { stats[0] = (float)red[0]; stats[1] = (float)red[256]; }
+    }
 }
 
 // per-column sums of an (M x C) matrix into out[C] (bias gradients); reuses the double partial slab

@@ -364,7 +364,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
 
 // ---- backward -----------------------------------------------------------------------------------------------
 int cnn_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
-                 hipEvent_t bucket_event, hipStream_t s)
+                 hipEvent_t bucket_event, hipStream_t s, float *stats)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
@@ -385,7 +385,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     };
     // head: dW2, db2, dd1 (gated by dense's ReLU6)
     {
-        const int rc = run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s);
+        // the MFMA head kernel also leaves the dense bias gradient (column sums of dd1) and the loss / accuracy sums
+        const bool fuse = head_bwd_fuses(m);
+        const int rc = run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s, fuse ? grads + m->o_db : nullptr, w.loss_i, w.correct_i,
+                                    fuse ? stats : nullptr);
         if (rc) return rc;
     }
     // dense 256->128: bias grad (column sums), wgrad, dgrad -> da4 (gradient w.r.t. the dropped, flattened map)
@@ -396,8 +399,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s2);
         int nblk, rows;
         stat_grid(B, 128, nblk, rows);
-        KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
-        KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
+        if (!head_bwd_fuses(m)) {
+            KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
+            KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
+        }
         if (g_matrix_precision == 1) launch_bf16<128, 128, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.dd1, w.wsp[2], nullptr, w.da4, g, s);
         else launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
     }
@@ -674,20 +679,23 @@ int run_head(const kws_model *m, int B, const float *params, const float *x, flo
     return KWS_OK;
 }
 
+bool head_bwd_fuses(const kws_model *m) { return m->head_K % 16 == 0 && m->head_K <= 128 && m->C <= 48; }
+
 int run_head_bwd(const kws_model *m, int B, const float *params, const float *x, const float *dlogits, float *dx,
-                 float *grads, bool relu6_gate, hipStream_t s)
+                 float *grads, bool relu6_gate, hipStream_t s, float *dx_colsum, const float *loss_i, const float *correct_i,
+                 float *stats)
 {
     const int K = m->head_K;
     const size_t smem = sizeof(float) * (size_t)(kHeadBwdRows * K + kHeadBwdRows * m->C);
-    if (K % 16 == 0 && K <= 128 && m->C <= 48) {    // the MFMA form: W2, a 16-sample tile and dlogits padded to 48 classes live in LDS
+    if (head_bwd_fuses(m)) {    // the MFMA form: W2, a 16-sample tile and dlogits padded to 48 classes live in LDS
         constexpr int G = 1;                          // 16-sample groups per block (4 measured slower: 64 blocks expose each group's staging latency)
         const size_t smem_fast = sizeof(float) * (size_t)(16 * (K + 2) + (16 + K) * 50);
         if (relu6_gate)
             KWS_LAUNCH("head_bwd_kernel", (head_bwd_mfma_kernel<true, G>), dim3(blocks_for(B, 16 * G)), dim3(256), smem_fast, s, x, params + m->o_hk, dlogits,
-                       dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
+                       dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C, dx_colsum, loss_i, correct_i, stats);
         else
             KWS_LAUNCH("head_bwd_kernel", (head_bwd_mfma_kernel<false, G>), dim3(blocks_for(B, 16 * G)), dim3(256), smem_fast, s, x, params + m->o_hk, dlogits,
-                       dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
+                       dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C, dx_colsum, loss_i, correct_i, stats);
         KWS_LAUNCH_CHECK("head backward");
         return KWS_OK;
     }
@@ -830,12 +838,15 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
               : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s);
     if (rc) return rc;
     // Keras reduces the per-sample losses with a batch mean (train.py:75-77): d(mean)/d(logits) carries 1/B
+    // simple_cnn: the head's backward kernel also sums the per-sample losses (no separate loss_reduce launch)
+    const bool fuse_stats = !lite && head_bwd_fuses(m);
     rc = run_head(m, a->B, a->params, w.d1, w.loss_i, w.correct_i, a->labels, a->class_weights, a->probs, nullptr, w.dlogits,
-                  a->grad_scale / (float)a->B, a->stats, a->ignore_index, s);
+                  a->grad_scale / (float)a->B, fuse_stats ? nullptr : a->stats, a->ignore_index, s);
     if (rc) return rc;
     if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
     return lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
-                : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s);
+                : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s,
+                               fuse_stats ? a->stats : nullptr);
 }
 
 int kws_set_matrix_precision(int mode)

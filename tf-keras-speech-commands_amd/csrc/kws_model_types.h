@@ -69,8 +69,12 @@ namespace kws {
 int run_head(const kws_model *m, int B, const float *params, const float *x, float *loss_i, float *correct_i,
              const int32_t *labels, const float *class_w, float *probs, int32_t *argmax, float *dlogits, float grad_scale,
              float *stats, int ignore_index, hipStream_t s);
+// dx_colsum / stats: optional extras the MFMA form of the kernel produces on the way (bias gradient of the layer in front of
+// the head; {sum loss, sum correct} from loss_i / correct_i).  head_bwd_fuses(m) tells whether that form applies.
+bool head_bwd_fuses(const kws_model *m);
 int run_head_bwd(const kws_model *m, int B, const float *params, const float *x, const float *dlogits, float *dx,
-                 float *grads, bool relu6_gate, hipStream_t s);
+                 float *grads, bool relu6_gate, hipStream_t s, float *dx_colsum = nullptr, const float *loss_i = nullptr,
+                 const float *correct_i = nullptr, float *stats = nullptr);
 
 // simple_gru (kws_rnn.hip)
 size_t gru_workspace_bytes(const kws_model *m, int B, bool training);

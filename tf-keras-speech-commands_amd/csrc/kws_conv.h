@@ -378,6 +378,169 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient in the split-precision form: dW[tap][ci][co] += sum_m x[pix(m) + tap][ci] * dz[m][co].
+// The reduction index is the output pixel m, the STRIDED dimension of both NHWC operands.  A chunk of 32 pixels is staged
+// in its natural [pixel][channel] order as three bf16 planes (one ds_write_b64 per plane and float4), and the MFMA operands
+// are fetched with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 channels and lane j
+// receives channel j of the 4 rows).  Lane group kg takes pixels 4kg..4kg+3 and 16+4kg..16+4kg+3 of the chunk as its 8
+// k-values (the same order for both operands), so a 32-lane half reads 8 consecutive rows; with a row stride of 8*odd words
+// these fall into 8 different bank octets.  Block = (tap, pixel range); the 9 taps of a range are given to the same XCD so
+// dz and the overlapping x rows are shared in its L2.  The block owns the whole (CIN x COUT) tile of its tap: waves split
+// COUT, every wave keeps all CIN/16 row tiles; the tile is gathered in LDS at the end and added with contiguous atomics.
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int tr_row_words(int C) { return ((C / 2 / 8) & 1) ? C / 2 : C / 2 + 8; }   // words per [pixel] row: 8 * odd
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char *p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dzp,
+                                                                  float *__restrict__ dw, const float *__restrict__ zero_page,
+                                                                  ConvGeom g, int chunks_per_block, int nranges)
+{
+    constexpr int KC = 32;                                        // pixels per chunk
+    constexpr int XS = 4 * tr_row_words(CIN), DS = 4 * tr_row_words(COUT);   // row strides in bytes
+    constexpr int MT = CIN / 16, NT = COUT / 16, NW = NT / 4;     // row tiles, column tiles, column tiles per wave
+    constexpr int XU = KC * CIN / 4, DU = KC * COUT / 4;          // float4 units of a chunk
+    constexpr int NXU = XU / 256, NDU = DU / 256;
+    static_assert(COUT % 64 == 0 && CIN % 32 == 0, "four waves split COUT in 16-column tiles; every thread stages whole units");
+    static_assert(3 * KC * (XS + DS) >= CIN * COUT * 4, "the staging space also holds the block's tile at the end");
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    unsigned char *Xs = wsm;                                      // [3][KC][XS]
+    unsigned char *Ds = wsm + 3 * KC * XS;                        // [3][KC][DS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
+    const int HW = g.Ho * g.Wo;
+    const long M = (long)g.B * HW;
+    const int ntaps = g.KH * g.KW;
+    // block id -> (tap, range): XCD = id % 8 holds every tap of its ranges
+    const int bid = blockIdx.x, tap = (bid >> 3) % ntaps, range = (bid / (8 * ntaps)) * 8 + (bid & 7);
+    const int kh = tap / g.KW, kw = tap % g.KW;
+    const long nchunk_all = (M + KC - 1) / KC, chunk0 = (long)range * chunks_per_block;
+    const int nchunks = (range >= nranges || chunk0 >= nchunk_all) ? 0
+                        : (int)(chunk0 + chunks_per_block <= nchunk_all ? chunks_per_block : nchunk_all - chunk0);
+
+    f32x4 acc[MT][NW];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nw = 0; nw < NW; ++nw) acc[mt][nw] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging units: unit u -> float4 e = u % (C/4) of pixel p = u / (C/4): coalesced global reads, contiguous LDS rows.
+    // The unit's clip and pixel-in-clip advance by 32 pixels per chunk without divisions; rows past M and taps that fall
+    // into the padding read the zero page.
+    const float rWo = 1.0f / (float)g.Wo;
+    int xb[NXU], xpix[NXU];
+#pragma unroll
+    for (int j = 0; j < NXU; ++j) {
+        const long m = chunk0 * KC + (tid + 256 * j) / (CIN / 4);
+        xb[j] = (int)(m / HW); xpix[j] = (int)(m - (long)xb[j] * HW);
+    }
+    struct Staged { f32x4 x[NXU], d[NDU]; };
+    auto load_chunk = [&](int ch, Staged &st) {
+        const long m0 = (chunk0 + ch) * KC;
+#pragma unroll
+        for (int j = 0; j < NXU; ++j) {
+            const int e = (tid + 256 * j) % (CIN / 4);
+            const int oy = (int)(((float)xpix[j] + 0.5f) * rWo), ox = xpix[j] - oy * g.Wo;
+            const int sy = oy * g.stride + kh - g.pt, sx = ox * g.stride + kw - g.pl;
+            const bool ok = xb[j] < g.B && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
+            const float *p = ok ? x + (((long)xb[j] * g.H + sy) * g.W + sx) * CIN + 4 * e : zero_page;
+            st.x[j] = *reinterpret_cast<const f32x4 *>(p);
+            xpix[j] += KC;
+            while (xpix[j] >= HW) { xpix[j] -= HW; ++xb[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < NDU; ++j) {
+            const int u = tid + 256 * j;
+            const long m = m0 + u / (COUT / 4);
+            const float *p = m < M ? dzp + m * COUT + 4 * (u % (COUT / 4)) : zero_page;
+            st.d[j] = *reinterpret_cast<const f32x4 *>(p);
+        }
+    };
+    auto store_chunk = [&](const Staged &st) {
+#pragma unroll
+        for (int j = 0; j < NXU; ++j) {
+            const int u = tid + 256 * j, o = (u / (CIN / 4)) * XS + 8 * (u % (CIN / 4));
+            bf16x4 h, m, l;
+            split_bf16(st.x[j], h, m, l);
+            *reinterpret_cast<bf16x4 *>(Xs + o) = h;
+            *reinterpret_cast<bf16x4 *>(Xs + KC * XS + o) = m;
+            *reinterpret_cast<bf16x4 *>(Xs + 2 * KC * XS + o) = l;
+        }
+#pragma unroll
+        for (int j = 0; j < NDU; ++j) {
+            const int u = tid + 256 * j, o = (u / (COUT / 4)) * DS + 8 * (u % (COUT / 4));
+            bf16x4 h, m, l;
+            split_bf16(st.d[j], h, m, l);
+            *reinterpret_cast<bf16x4 *>(Ds + o) = h;
+            *reinterpret_cast<bf16x4 *>(Ds + KC * DS + o) = m;
+            *reinterpret_cast<bf16x4 *>(Ds + 2 * KC * DS + o) = l;
+        }
+    };
+    // transposed fragment: lane 4q+pp of a group supplies row q, channels 4pp..4pp+3 of the 16-channel tile
+    const int trq = li >> 2, trp = li & 3;
+    const unsigned char *xfrag = Xs + (4 * lq + trq) * XS + 8 * trp;
+    const unsigned char *dfrag = Ds + (4 * lq + trq) * DS + 8 * trp + 32 * (wave * NW);
+    auto frag = [&](const unsigned char *base, int stride, int plane, int tile) -> bf16x8 {
+        union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+        u.s.lo = lds_read_tr16(base + plane * KC * stride + 32 * tile);
+        u.s.hi = lds_read_tr16(base + plane * KC * stride + 32 * tile + 16 * stride);
+        return u.v;
+    };
+
+    auto mma_chunk = [&]() {
+        bf16x8 b[NW][3];
+#pragma unroll
+        for (int nw = 0; nw < NW; ++nw)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) b[nw][p] = frag(dfrag, DS, p, nw);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 a[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) a[p] = frag(xfrag, XS, p, mt);
+#pragma unroll
+            for (int nw = 0; nw < NW; ++nw) acc[mt][nw] = mfma_bf16x6(a, b[nw], acc[mt][nw]);
+        }
+    };
+    // two chunks of global loads in flight (two register sets, loop unrolled by two): the nine tap blocks of a range
+    // fetch the same lines, so per range only one chunk's worth of bytes is outstanding and one MFMA phase does not
+    // cover a miss
+    Staged s0, s1;
+    if (nchunks > 0) load_chunk(0, s0);
+    if (nchunks > 1) load_chunk(1, s1);
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        __syncthreads();
+        store_chunk(s0);
+        __syncthreads();
+        if (ch + 2 < nchunks) load_chunk(ch + 2, s0);
+        mma_chunk();
+        if (ch + 1 < nchunks) {
+            __syncthreads();
+            store_chunk(s1);
+            __syncthreads();
+            if (ch + 3 < nchunks) load_chunk(ch + 3, s1);
+            mma_chunk();
+        }
+    }
+    // gather the block's (CIN x COUT) tile in LDS (reusing the staging space) and add it with contiguous atomics
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(wsm);                   // [CIN][COUT]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nw = 0; nw < NW; ++nw)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(16 * mt + 4 * lq + r) * COUT + 16 * (wave * NW + nw) + li] = acc[mt][nw][r];
+    __syncthreads();
+    if (nchunks > 0)
+        for (int i = tid; i < CIN * COUT; i += 256) atomicAdd(dw + (long)tap * CIN * COUT + i, red[i]);
+}
+
 // N consecutive floats with the widest aligned load (N = 1, 2, 4, 8); p must be N*4-byte aligned (16 for N = 8)
 template <int N>
 __device__ __forceinline__ void load_vec(const float *__restrict__ p, float (&v)[N])
@@ -833,6 +996,146 @@ __global__ __launch_bounds__(256) void conv_fwd_clip_kernel(const float *__restr
             const double v = (red[(0 * 2 + which) * COUT + c] + red[(1 * 2 + which) * COUT + c]) +
                              (red[(2 * 2 + which) * COUT + c] + red[(3 * 2 + which) * COUT + c]);
             partial[((long)which * COUT + c) * partial_stride + blockIdx.x] = v;
+        }
+    }
+}
+
+// The same forward on the bf16 matrix cores in the three-way split form (default precision, see mfma_bf16x6): K = 32 of one
+// MFMA covers TWO taps x 16 input channels (k = 8 lq + j: lane group lq < 2 reads tap 2s, lq >= 2 tap 2s + 1, channels
+// 8 (lq & 1) + j), five k-steps for the nine taps (the tenth half is zero weights).  The clip's haloed map is split into
+// bf16 planes while it is staged, laid out [plane][channel half][halo pixel][8] so that an A fragment is one ds_read_b128
+// per plane and 16 consecutive pixels fill the 64 banks.  Waves split (column tile, tile parity): each keeps the 5 x 3
+// weight fragments of ITS 16 output channels in registers, and the 10 pixel tiles of a 15 x 10 map divide evenly (the fp32
+// form gave its four waves 3, 3, 2, 2 tiles).  30 MFMAs of 16 cycles per tile and wave against 72 of 32.
+template <bool STATS, bool POOLED = false>
+__global__ __launch_bounds__(256, 2) void conv_fwd_clip_bf16_kernel(const float *__restrict__ x, const float *__restrict__ wgt,
+                                                                     float *__restrict__ z, int B, int H, int W,
+                                                                     double *__restrict__ partial, int partial_stride,
+                                                                     const float *__restrict__ scale = nullptr,
+                                                                     const float *__restrict__ shift = nullptr)
+{
+    constexpr int CIN = 16, COUT = 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ctile[];   // [3 planes][2 halves][(H+2)(W+2)][8 bf16], zero halo
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lq = lane >> 4;
+    const int nt = wave & 1, tpar = wave >> 1;
+    const int HP = H + 2, WP = W + 2, HW = H * W, NPIX = HP * WP;
+    const int W2 = W / 2, n2 = (H / 2) * W2;                       // pool windows (POOLED)
+    const int ntile = POOLED ? (n2 + 3) / 4 : (HW + 15) / 16;
+    for (int i = threadIdx.x; i < 6 * NPIX * 4; i += 256) reinterpret_cast<unsigned *>(ctile)[i] = 0u;
+    const float sc = POOLED ? scale[16 * nt + li] : 1.f, sh = POOLED ? shift[16 * nt + li] : 0.f;
+
+    // B fragments of k-step s: lane holds W[tap][8 (lq & 1) + j][16 nt + li], tap = 2 s + (lq >> 1) (zero past tap 8)
+    bf16x8 wf[5][3];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int tap = 2 * st + (lq >> 1);
+        f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = {0.f, 0.f, 0.f, 0.f};
+        if (tap < 9) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w0[j] = wgt[(tap * CIN + 8 * (lq & 1) + j) * COUT + 16 * nt + li];
+                w1[j] = wgt[(tap * CIN + 8 * (lq & 1) + 4 + j) * COUT + 16 * nt + li];
+            }
+        }
+        bf16x4 h0, m0, l0, h1, m1, l1;
+        split_bf16(w0, h0, m0, l0);
+        split_bf16(w1, h1, m1, l1);
+        wf[st][0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        wf[st][1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+        wf[st][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    // byte offset of this lane's A fragment of k-step s from its pixel's tap-(0,0) position: tap shift + channel half
+    int aoff[5];
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int tap = 2 * st + (lq >> 1), tc = tap < 9 ? tap : 8;
+        aoff[st] = (((lq & 1) * NPIX) + (tc / 3) * WP + tc % 3) * 16;
+    }
+
+    constexpr int PF = 3;                                         // float4 per thread for the next clip (<= 768 per clip)
+    const int nf4 = HW * (CIN / 4);
+    f32x4 pf[PF];
+    auto prefetch = [&](int b) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(x + (long)b * HW * CIN);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) { const int i = threadIdx.x + 256 * j; pf[j] = i < nf4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    };
+    auto stage = [&](int i, f32x4 v) {                            // float4 i of the clip = channels 4 c4.. of pixel i / 4
+        const int pix = i >> 2, c4 = i & 3, y = pix / W, xx = pix - y * W;
+        bf16x4 h, m, l;
+        split_bf16(v, h, m, l);
+        unsigned char *d = ctile + (((c4 >> 1) * NPIX + (y + 1) * WP + xx + 1) * 16 + (c4 & 1) * 8);
+        *reinterpret_cast<bf16x4 *>(d) = h;
+        *reinterpret_cast<bf16x4 *>(d + 2 * NPIX * 16) = m;
+        *reinterpret_cast<bf16x4 *>(d + 4 * NPIX * 16) = l;
+    };
+    float ssum = 0.f, ssq = 0.f;
+
+    if ((int)blockIdx.x < B) prefetch(blockIdx.x);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nf4) stage(i, pf[j]);
+        }
+        if (nf4 > 256 * PF) {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(x + (long)b * HW * CIN);
+            for (int i = threadIdx.x + 256 * PF; i < nf4; i += 256) stage(i, src[i]);
+        }
+        __syncthreads();
+        if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
+        for (int t = tpar; t < ntile; t += 2) {
+            int oh, ow;
+            if (POOLED) {                                            // A row li = element li & 3 of window 4 t + (li >> 2)
+                int wq = 4 * t + (li >> 2);
+                wq = wq < n2 ? wq : 0;
+                oh = 2 * (wq / W2) + ((li & 3) >> 1);
+                ow = 2 * (wq % W2) + (li & 1);
+            } else {
+                const int p = 16 * t + li, pc = p < HW ? p : HW - 1;
+                oh = pc / W; ow = pc % W;
+            }
+            const unsigned char *a0 = ctile + (oh * WP + ow) * 16;   // tap (0,0) of this pixel in halo coordinates
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 5; ++st) {
+                bf16x8 a[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(a0 + aoff[st] + p * 2 * NPIX * 16);
+                acc = mfma_bf16x6(a, wf[st], acc);
+            }
+            if (POOLED) {
+                const int wd = 4 * t + lq;                          // this lane's four rows are the elements of window wd
+                if (wd < n2) {
+                    const float m = fmaxf(fmaxf(fmaf(acc[0], sc, sh), fmaf(acc[1], sc, sh)), fmaxf(fmaf(acc[2], sc, sh), fmaf(acc[3], sc, sh)));
+                    z[((long)b * n2 + wd) * COUT + 16 * nt + li] = relu6f(m);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int po = 16 * t + 4 * lq + r;
+                if (po < HW) {
+                    const float v = acc[r];
+                    z[((long)b * HW + po) * COUT + 16 * nt + li] = v;
+                    if (STATS) { ssum += v; ssq = fmaf(v, v, ssq); }
+                }
+            }
+        }
+    }
+    if (STATS) {
+        // lanes with equal li hold the same column: reduce over lq (xor 16, 32), then over the two waves of the column tile
+        __syncthreads();
+        double *red = reinterpret_cast<double *>(ctile);         // [4 waves][2][16]
+        double a = (double)ssum, q = (double)ssq;
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        if (lq == 0) { red[(wave * 2 + 0) * 16 + li] = a; red[(wave * 2 + 1) * 16 + li] = q; }
+        __syncthreads();
+        if (threadIdx.x < 2 * COUT) {
+            const int which = threadIdx.x / COUT, c = threadIdx.x % COUT, n = c / 16, l = c % 16;
+            partial[((long)which * COUT + c) * partial_stride + blockIdx.x] = red[(n * 2 + which) * 16 + l] + red[((n + 2) * 2 + which) * 16 + l];
         }
     }
 }

@@ -30,6 +30,27 @@ __device__ __forceinline__ double block_sum_partials(const double *__restrict__ 
     return s;
 }
 
+// the same sum by ONE wave (64-thread block), no LDS and no barriers: the finalize kernels sit between every producer and
+// consumer of the main chain, often while persistent LDS-filling kernels of the side stream own the CUs -- a block that
+// needs no LDS is placed at once (the 256-thread LDS form waited up to 28 us for a slot) and a wave reduces faster than
+// eight block barriers.  Four independent loads per lane and trip; fixed order, so the result is deterministic.
+__device__ __forceinline__ double wave_sum_partials(const double *__restrict__ partial, int which, int C, int c, int nblk)
+{
+    const double *p = partial + ((long)which * C + c) * kStatStride;
+    const int lane = threadIdx.x & 63;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int b = lane; b < nblk; b += 256) {
+        s0 += p[b];
+        s1 += b + 64 < nblk ? p[b + 64] : 0.0;
+        s2 += b + 128 < nblk ? p[b + 128] : 0.0;
+        s3 += b + 192 < nblk ? p[b + 192] : 0.0;
+    }
+    double s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+
 // ---- per-channel sums over the rows of an (M x C) matrix, in double -------------------------------------------
 // partial[(0*C + c)*kStatStride + blk] = sum, [(1*C + c)*kStatStride + blk] = sum of squares.  C divides 256.
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float *__restrict__ z, long M, int C, int rows_per_block,
@@ -70,10 +91,9 @@ __global__ void bn_finalize_train_kernel(const double *__restrict__ partial, int
                                          const float *__restrict__ gamma, const float *__restrict__ beta,
                                          float *__restrict__ moving_mean, float *__restrict__ moving_var, BnCoef k)
 {
-    __shared__ double sh[256];
-    const int c = blockIdx.x;            // one 256-thread block per channel
-    const double s = block_sum_partials(partial, 0, C, c, nblk, sh);
-    const double ss = block_sum_partials(partial, 1, C, c, nblk, sh);
+    const int c = blockIdx.x;            // one wave per channel
+    const double s = wave_sum_partials(partial, 0, C, c, nblk);
+    const double ss = wave_sum_partials(partial, 1, C, c, nblk);
     if (threadIdx.x != 0) return;
     const double mean = s / (double)M;
     double var = ss / (double)M - mean * mean;
@@ -277,10 +297,9 @@ __global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int n
                                        const float *__restrict__ gamma, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, BnCoef k)
 {
-    __shared__ double sh[256];
-    const int c = blockIdx.x;
-    const double s = block_sum_partials(partial, 0, C, c, nblk, sh);
-    const double sx = block_sum_partials(partial, 1, C, c, nblk, sh);
+    const int c = blockIdx.x;            // one wave per channel
+    const double s = wave_sum_partials(partial, 0, C, c, nblk);
+    const double sx = wave_sum_partials(partial, 1, C, c, nblk);
     if (threadIdx.x != 0) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)sx;

@@ -3,6 +3,7 @@
 // Topology follows classifier/models/cnn.py:27-66 (SimpleCNN) and the softmax head of classifier/model.py:37.
 // Flat buffers: `params` holds the trainable tensors and `state` the BatchNormalization moving statistics, both
 // in Keras get_weights() order (kws_model_tensor_info lists name / shape / offset); `grads` mirrors `params`.
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -152,6 +153,28 @@ void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g,
                s, x, dz, dw, zero_page(), g, spw);
 }
 
+// dW += wgrad(x, dz) in the split-precision form (conv_wgrad_bf16_kernel): grid = ntaps * (pixel ranges), one resident round
+// of 2 blocks per CU, the taps of a range on one XCD.
+template <int CIN, int COUT>
+void launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s)
+{
+    constexpr size_t stage = (size_t)3 * 32 * 4 * (tr_row_words(CIN) + tr_row_words(COUT)), tile = (size_t)CIN * COUT * sizeof(float);
+    constexpr size_t smem = stage > tile ? stage : tile;
+    static const int occ = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        return resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT>, 256, smem);
+    }();
+    const long M = (long)g.B * g.Ho * g.Wo, nchunk = (M + 31) / 32;
+    const int ntaps = g.KH * g.KW;
+    // ranges: a multiple of 8 (one per XCD), at most one resident round, at least 4 chunks per block
+    long nranges = std::max<long>(8, ((long)cu_count() * occ / ntaps) / 8 * 8);
+    nranges = std::min<long>(nranges, std::max<long>(8, (nchunk / 4 + 7) / 8 * 8));
+    const int cpb = (int)((nchunk + nranges - 1) / nranges);
+    static const std::string name = "conv_wgrad_bf16<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
+    KWS_LAUNCH(name.c_str(), (conv_wgrad_bf16_kernel<CIN, COUT>), dim3((unsigned)(nranges * ntaps)), dim3(256), smem, s, x, dz, dw,
+               zero_page(), g, cpb, (int)nranges);
+}
+
 // dx <- dgrad(dz): ONE launch over every stride-parity class of the input pixels (blockIdx.y = class).  MW (16-row tiles
 // per wave) is picked so that the waves divide evenly over the SIMDs: every SIMD's matrix pipe then runs
 // ceil(waves / SIMDs) * MW tile-times, and the smallest such product wins (ties: the larger MW reuses weights more).
@@ -287,7 +310,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         if (training) {
             if (l1m) KWS_LAUNCH("l1m_stats_kernel", l1m_stats_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, B, d.H0, d.W0, cpw, w.partial);
             else KWS_LAUNCH("l1_stats_kernel", l1_stats_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, B, d.H0, d.W0, cpb, w.partial);
-            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", 1), bn_finalize_train_kernel, dim3(16), dim3(256), 0, s, w.partial, l1m ? nbm : nb, M1, 16,
+            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", 1), bn_finalize_train_kernel, dim3(16), dim3(64), 0, s, w.partial, l1m ? nbm : nb, M1, 16,
                        params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1);
         }
         if (l1m) KWS_LAUNCH("l1m_act_pool_kernel", l1m_act_pool_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
@@ -305,10 +328,20 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             // conv2: clip-resident kernel, batch statistics fused into the epilogue when training
             const unsigned nblk = (unsigned)std::min(B, kMaxStatBlocks);
             const size_t sm = std::max(sizeof(float) * (size_t)(Hs[1] + 2) * (Ws[1] + 2) * 20, sizeof(double) * 4 * 2 * 32);
-            if (training) {
+            const size_t smb = std::max((size_t)6 * 16 * (Hs[1] + 2) * (Ws[1] + 2), sizeof(double) * 4 * 2 * 16);
+            if (training && bf16) {
+                KWS_LAUNCH("conv_fwd_clip_bf16<16,32>", (conv_fwd_clip_bf16_kernel<true>), dim3(nblk), dim3(256), smb, s, in, kern, w.z[1], B, Hs[1],
+                           Ws[1], w.partial, kStatStride);
+                fused_stat_blocks = (int)nblk;
+            } else if (training) {
                 KWS_LAUNCH("conv_fwd_clip<16,32>", (conv_fwd_clip_kernel<32, true>), dim3(nblk), dim3(256), sm, s, in, kern, w.z[1], B, Hs[1], Ws[1],
                            w.partial, kStatStride);
                 fused_stat_blocks = (int)nblk;
+            } else if (bf16) {
+                const BnCoef k2 = coef_of(w.coef[1], 32);
+                KWS_LAUNCH("conv_fwd_clip_pool_bf16<16,32>", (conv_fwd_clip_bf16_kernel<false, true>), dim3(nblk), dim3(256), smb, s, in, kern, w.a[1], B,
+                           Hs[1], Ws[1], w.partial, kStatStride, k2.scale, k2.shift);
+                continue;
             } else {
                 // inference: BatchNorm affine + ReLU6 + 2x2 max in the kernel's epilogue, a2 written directly
                 const BnCoef k2 = coef_of(w.coef[1], 32);
@@ -339,7 +372,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             stat_grid(M, C, nblk, rows);
             if (fused_stat_blocks) nblk = fused_stat_blocks;
             else KWS_LAUNCH(prof_name("channel_stats_kernel", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
-            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
+            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(C), dim3(64), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                                params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
         }
         const float rate = (training && l == 3 && seed != 0) ? 0.5f : 0.f;   // Dropout(0.5) after Flatten, cnn.py:63
@@ -423,7 +456,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         } else
             KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
                        rows, w.partial, rate, slo, shi);
-        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
+        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                    grads + m->o_g[l], grads + m->o_b[l], k);
         if (l == 1)
             ;                                                   // fused into conv_dgrad_clip's staging below
@@ -440,7 +473,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
-            launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);
+            if (g_matrix_precision == 1) launch_wgrad_bf16<64, 128>(in, w.gz[3], dk, g, s2);
+            else launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);
             if (bucket_event) {
                 // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here: it
                 // runs the dense and conv4 weight gradients in order and joined the caller's stream at fork(3), i.e. after
@@ -482,16 +516,28 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         const long M1 = (long)B * d.H0 * d.W0;
         BnCoef k1 = coef_of(w.coef[0], 16);
         const float *kern1 = params + m->o_k[0];
-        if (l1m) KWS_LAUNCH("l1m_bwd_reduce_kernel", l1m_bwd_reduce_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
-                   cpw, w.partial);
-        else KWS_LAUNCH("l1_bwd_reduce_kernel", l1_bwd_reduce_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
-                   cpb, w.partial);
-        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(256), 0, s, w.partial, l1m ? nbm : nb, M1, 16,
-                   params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], k1);
-        if (l1m) KWS_LAUNCH("l1m_bwd_wgrad_kernel", l1m_bwd_wgrad_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
-                   grads + m->o_k[0], B, d.H0, d.W0, cpw);
-        else KWS_LAUNCH("l1_bwd_wgrad_kernel", l1_bwd_wgrad_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
-                   grads + m->o_k[0], B, d.H0, d.W0, cpb);
+        static const bool two_pass = getenv("KWS_L1_TWO_PASS") != nullptr;     // A/B switch (measurement only)
+        if (l1m && two_pass) {
+            KWS_LAUNCH("l1m_bwd_reduce_kernel", l1m_bwd_reduce_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
+                       cpw, w.partial);
+            KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(64), 0, s, w.partial, nbm, M1, 16,
+                       params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], k1);
+            KWS_LAUNCH("l1m_bwd_wgrad_kernel", l1m_bwd_wgrad_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
+                       grads + m->o_k[0], B, d.H0, d.W0, cpw);
+        } else if (l1m) {
+            // single pass: every sum the closed form of dW1 needs (kws_layer1.h), then one small finalize launch
+            KWS_LAUNCH("l1m_bwd_fused_kernel", l1m_bwd_fused_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0, cpw,
+                       w.partial);
+            KWS_LAUNCH("l1_bwd_finalize_kernel", l1_bwd_finalize_kernel, dim3(kL1Rows), dim3(64), 0, s, w.partial, nbm, (double)M1, kern1,
+                       params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], grads + m->o_k[0], k1);
+        } else {
+            KWS_LAUNCH("l1_bwd_reduce_kernel", l1_bwd_reduce_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
+                       cpb, w.partial);
+            KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(64), 0, s, w.partial, nb, M1, 16,
+                       params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], k1);
+            KWS_LAUNCH("l1_bwd_wgrad_kernel", l1_bwd_wgrad_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
+                       grads + m->o_k[0], B, d.H0, d.W0, cpb);
+        }
     }
     KWS_HIP_CHECK(hipEventRecord(sync_event(9), s2));             // join: every wgrad is part of the caller's stream order again
     KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(9), 0));
@@ -549,7 +595,7 @@ int lite_forward(const kws_model *m, const float *feat, int B, const float *para
             int nblk, rows;
             stat_grid(M, C, nblk, rows);
             KWS_LAUNCH(prof_name("channel_stats_kernel", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], M, C, rows, w.partial);
-            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C,
+            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", l + 1), bn_finalize_train_kernel, dim3(C), dim3(64), 0, s, w.partial, nblk, M, C,
                        params + m->o_g[l], params + m->o_b[l], state + m->o_mm[l], state + m->o_mv[l], k);
         }
         const float rate = (training && l == 3 && seed != 0) ? 0.5f : 0.f;
@@ -603,7 +649,7 @@ int lite_backward(const kws_model *m, const float *feat, int B, const float *par
         else
             KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B,
                        Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);
-        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, M, C,
+        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, w.partial, nblk, M, C,
                    params + m->o_g[l], grads + m->o_g[l], grads + m->o_b[l], k);
         if (l >= 2)      // sepconv3 and sepconv4 carry activation='relu' (cnn.py:113,122)
             KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<true>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l],

@@ -1249,6 +1249,119 @@ __global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(float *__restrict_
     }
 }
 
+// The conv2 data gradient on the bf16 matrix cores in the three-way split form: K = 32 of one MFMA is one tap x the 32
+// output channels (k = 8 lq + j), nine k-steps.  dz (formed from g and z on the way in when BN) is split into bf16 planes
+// while it is staged, laid out [plane][channel quarter][halo pixel][8]: an A fragment is one ds_read_b128 per plane and 16
+// consecutive pixels fill the 64 banks.  The 9 x 3 weight fragments W[tap][n = li][8 lq ..] stay in registers (256-register
+// budget, two blocks per CU).  The ten pixel tiles of a 15 x 10 map do not divide over four waves, so the tile a wave
+// starts with rotates from clip to clip and every SIMD sees the same load over time.
+template <bool BN>
+__global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__restrict__ dz, const float *__restrict__ wgt,
+                                                                       float *__restrict__ dx, int B, int H, int W, BnBwdArgs bn)
+{
+    constexpr int CR = 32, CO = 16, F4 = CR / 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char ctile[];   // [3 planes][4 quarters][(H+2)(W+2)][8 bf16], zero halo
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lq = lane >> 4;
+    const int HP = H + 2, WP = W + 2, HW = H * W, NPIX = HP * WP, ntile = (HW + 15) / 16;
+    for (int i = threadIdx.x; i < 12 * NPIX * 4; i += 256) reinterpret_cast<unsigned *>(ctile)[i] = 0u;
+
+    bf16x8 wf[9][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wgt + (t * CO + li) * CR + 8 * lq);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(wgt + (t * CO + li) * CR + 8 * lq + 4);
+        bf16x4 h0, m0, l0, h1, m1, l1;
+        split_bf16(w0, h0, m0, l0);
+        split_bf16(w1, h1, m1, l1);
+        wf[t][0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        wf[t][1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+        wf[t][2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+
+    constexpr int PF = 5;                                         // float4 held per thread for the next clip (<= 1280 per clip)
+    const int nf4 = HW * F4;
+    f32x4 pf[PF], pz[PF];
+    float gi[4], mean[4], inv[4], k2[4], k3[4];                   // BN coefficients of this thread's 4 channels (c4 = threadIdx.x % F4)
+    if (BN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (threadIdx.x % F4) + e;
+            inv[e] = bn.inv[c]; gi[e] = bn.gamma[c] * inv[e]; mean[e] = bn.mean[c]; k2[e] = bn.k2[c]; k3[e] = bn.k3[c];
+        }
+    }
+    auto bn_apply = [&](f32x4 g, f32x4 zv) {
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = gi[e] * (g[e] - k2[e] - (zv[e] - mean[e]) * inv[e] * k3[e]);
+        return d;
+    };
+    auto prefetch = [&](int b) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(dz + (long)b * HW * CR);
+        const f32x4 *zs = reinterpret_cast<const f32x4 *>(bn.z + (long)b * HW * CR);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            pf[j] = i < nf4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (BN) pz[j] = i < nf4 ? zs[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&](int i, f32x4 v) {                            // float4 i of the clip = channels 4 c4.. of pixel i / 8
+        const int pix = i / F4, c4 = i % F4, y = pix / W, xx = pix - y * W;
+        bf16x4 h, m, l;
+        split_bf16(v, h, m, l);
+        unsigned char *d = ctile + (((c4 >> 1) * NPIX + (y + 1) * WP + xx + 1) * 16 + (c4 & 1) * 8);
+        *reinterpret_cast<bf16x4 *>(d) = h;
+        *reinterpret_cast<bf16x4 *>(d + 4 * NPIX * 16) = m;
+        *reinterpret_cast<bf16x4 *>(d + 8 * NPIX * 16) = l;
+    };
+    if ((int)blockIdx.x < B) prefetch(blockIdx.x);
+    int rot = wave;
+    for (int b = blockIdx.x; b < B; b += gridDim.x, ++rot) {
+        __syncthreads();                                          // previous clip's reads are done
+        f32x4 *dst = reinterpret_cast<f32x4 *>(dz + (long)b * HW * CR);
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nf4) {
+                f32x4 v = pf[j];
+                if (BN) { v = bn_apply(v, pz[j]); dst[i] = v; }
+                stage(i, v);
+            }
+        }
+        if (nf4 > 256 * PF) {                                     // larger clips: the remainder goes straight through
+            const f32x4 *zs = reinterpret_cast<const f32x4 *>(bn.z + (long)b * HW * CR);
+            for (int i = threadIdx.x + 256 * PF; i < nf4; i += 256) {
+                f32x4 v = dst[i];
+                if (BN) { v = bn_apply(v, zs[i]); dst[i] = v; }
+                stage(i, v);
+            }
+        }
+        __syncthreads();
+        if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);      // next clip's HBM latency hides under this clip's MFMAs
+        for (int t = rot & 3; t < ntile; t += 4) {
+            const int p = 16 * t + li, pc = p < HW ? p : HW - 1;  // A-fragment row (clamped: extra rows are not stored)
+            const int ih = pc / W, iw = pc % W;
+            // source pixel of tap (kh, kw) in halo coordinates: (ih + 1 - kh + 1, iw + 1 - kw + 1)
+            const unsigned char *a0 = ctile + (lq * NPIX + (ih + 2) * WP + iw + 2) * 16;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) a[pl] = *reinterpret_cast<const bf16x8 *>(a0 - (kh * WP + kw) * 16 + pl * 4 * NPIX * 16);
+                    acc = mfma_bf16x6(a, wf[kh * 3 + kw], acc);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int po = 16 * t + 4 * lq + r;
+                if (po < HW) dx[((long)b * HW + po) * CO + li] = acc[r];
+            }
+        }
+    }
+}
+
 // dW[tap][ci][co] += sum_pixels x[b][oh+kh-1][ow+kw-1][ci] * dz[b][oh][ow][co],  CIN = 16, COUT = 32, all 9 taps per wave
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_wgrad_clip_kernel(const float *__restrict__ x, const float *__restrict__ dz,

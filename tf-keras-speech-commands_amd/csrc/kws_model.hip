@@ -499,7 +499,13 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             // dgrad forms dz2 from (g, z2) while staging and leaves it in gz[1]; wgrad then overlaps with layer 1's kernels
             const size_t smd = sizeof(float) * (size_t)(H1 + 2) * (W1 + 2) * (32 + 4);
             const BnBwdArgs bn = {w.z[1], params + m->o_g[1], k.mean, k.inv, k.k2, k.k3};
-            KWS_LAUNCH("conv_dgrad_clip<32,16>", (conv_dgrad_clip_kernel<32, true>), dim3(nblk_d), dim3(256), smd, s, w.gz[1], kern, w.da[0], B, H1, W1, bn);
+            if (g_matrix_precision == 1) {
+                // split-precision form: 2 blocks per CU by registers (the weight fragments of all nine taps stay in them)
+                const size_t smdb = (size_t)12 * 16 * (H1 + 2) * (W1 + 2);
+                KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s, w.gz[1],
+                           kern, w.da[0], B, H1, W1, bn);
+            } else
+                KWS_LAUNCH("conv_dgrad_clip<32,16>", (conv_dgrad_clip_kernel<32, true>), dim3(nblk_d), dim3(256), smd, s, w.gz[1], kern, w.da[0], B, H1, W1, bn);
             if (int rc = fork(1)) return rc;
             KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);
         }

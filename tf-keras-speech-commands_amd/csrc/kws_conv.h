@@ -1362,6 +1362,124 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__r
     }
 }
 
+// The conv2 weight gradient on the bf16 matrix cores in the three-way split form.  The reduction runs over the clip's
+// pixels (k-steps of 32, the last one padded with a zero dz row), so both operands are transposed: the clip's haloed x map
+// and its dz are staged as bf16 planes in [pixel][16 channels] rows of 32 B (dz as two 16-channel halves) and fetched with
+// ds_read_b64_tr_b16; every lane supplies the address of one pixel row, so the tap shift of x is an immediate offset and
+// 8 consecutive pixels per 32-lane half fall into 8 different bank octets.  Wave = (column tile nt, tap parity): it keeps
+// the accumulators of its 5 or 4 taps for the whole kernel and reuses each dz fragment for all of them.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_clip_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dz,
+                                                                       float *__restrict__ dw, int B, int H, int W)
+{
+    constexpr int CIN = 16, COUT = 32, KS = 5;                    // k-steps of 32 pixels: H * W <= 160
+    extern __shared__ __attribute__((aligned(16))) unsigned char ctile[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lq = lane >> 4;
+    const int nt = wave & 1, tg = wave >> 1;
+    const int HP = H + 2, WP = W + 2, HW = H * W, NPIX = HP * WP;
+    const int XPL = NPIX * 32, DPL = (HW + 1) * 32;               // bytes per x plane, per dz (plane, half); dz row HW stays zero
+    unsigned char *Xs = ctile, *Ds = ctile + 3 * XPL;
+    for (int i = threadIdx.x; i < (3 * XPL + 6 * DPL) / 4; i += 256) reinterpret_cast<unsigned *>(ctile)[i] = 0u;
+
+    // per-lane row addresses of the transposing reads: lane 4q + pp of a 16-lane group supplies row q, channels 4pp..4pp+3;
+    // group lq takes pixels 4 lq + q (first read) and 16 + 4 lq + q (second read) of the k-step
+    int xaddr[KS][2], daddr[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int pq = 32 * ks + 16 * rd + 4 * lq + (li >> 2);
+            const bool ok = pq < HW;
+            const int oh = ok ? pq / W : 0, ow = ok ? pq - oh * W : 0;   // rows past the clip: any finite x row (dz row HW is zero)
+            xaddr[ks][rd] = (oh * WP + ow) * 32 + (li & 3) * 8;
+            daddr[ks][rd] = (ok ? pq : HW) * 32 + (li & 3) * 8 + nt * DPL;
+        }
+    auto frag = [&](const unsigned char *p0, const unsigned char *p1) -> bf16x8 {
+        union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+        u.s.lo = lds_read_tr16(p0);
+        u.s.hi = lds_read_tr16(p1);
+        return u.v;
+    };
+
+    f32x4 acc[5];                                                 // taps tg, tg + 2, ...: dW[tap][ci = 4 lq + r][co = 16 nt + li]
+#pragma unroll
+    for (int t = 0; t < 5; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int PX = 3, PD = 5;                                 // float4 per thread: x (<= 768 per clip), dz (<= 1280)
+    const int nx4 = HW * (CIN / 4), nd4 = HW * (COUT / 4);
+    f32x4 px[PX], pd[PD];
+    auto prefetch = [&](int b) {
+        const f32x4 *xs = reinterpret_cast<const f32x4 *>(x + (long)b * HW * CIN);
+        const f32x4 *ds = reinterpret_cast<const f32x4 *>(dz + (long)b * HW * COUT);
+#pragma unroll
+        for (int j = 0; j < PX; ++j) { const int i = threadIdx.x + 256 * j; px[j] = i < nx4 ? xs[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int j = 0; j < PD; ++j) { const int i = threadIdx.x + 256 * j; pd[j] = i < nd4 ? ds[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    };
+    auto stage_x = [&](int i, f32x4 v) {
+        const int pix = i >> 2, c4 = i & 3, y = pix / W, xx = pix - y * W;
+        bf16x4 h, m, l;
+        split_bf16(v, h, m, l);
+        unsigned char *d = Xs + ((y + 1) * WP + xx + 1) * 32 + c4 * 8;
+        *reinterpret_cast<bf16x4 *>(d) = h;
+        *reinterpret_cast<bf16x4 *>(d + XPL) = m;
+        *reinterpret_cast<bf16x4 *>(d + 2 * XPL) = l;
+    };
+    auto stage_d = [&](int i, f32x4 v) {
+        const int pix = i >> 3, c4 = i & 7;
+        bf16x4 h, m, l;
+        split_bf16(v, h, m, l);
+        unsigned char *d = Ds + (c4 >> 2) * DPL + pix * 32 + (c4 & 3) * 8;
+        *reinterpret_cast<bf16x4 *>(d) = h;
+        *reinterpret_cast<bf16x4 *>(d + 2 * DPL) = m;
+        *reinterpret_cast<bf16x4 *>(d + 4 * DPL) = l;
+    };
+    if ((int)blockIdx.x < B) prefetch(blockIdx.x);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PX; ++j) { const int i = threadIdx.x + 256 * j; if (i < nx4) stage_x(i, px[j]); }
+#pragma unroll
+        for (int j = 0; j < PD; ++j) { const int i = threadIdx.x + 256 * j; if (i < nd4) stage_d(i, pd[j]); }
+        if (nx4 > 256 * PX || nd4 > 256 * PD) {                   // larger clips: the remainder goes straight through
+            const f32x4 *xs = reinterpret_cast<const f32x4 *>(x + (long)b * HW * CIN);
+            for (int i = threadIdx.x + 256 * PX; i < nx4; i += 256) stage_x(i, xs[i]);
+            const f32x4 *ds = reinterpret_cast<const f32x4 *>(dz + (long)b * HW * COUT);
+            for (int i = threadIdx.x + 256 * PD; i < nd4; i += 256) stage_d(i, ds[i]);
+        }
+        __syncthreads();
+        if (b + (int)gridDim.x < B) prefetch(b + gridDim.x);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 bfr[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bfr[p] = frag(Ds + 2 * p * DPL + daddr[ks][0], Ds + 2 * p * DPL + daddr[ks][1]);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int tap = tg + 2 * t;                        // wave-uniform; tg = 1 has four taps
+                if (tap < 9) {
+                    const int toff = ((tap / 3) * WP + tap % 3) * 32;
+                    bf16x8 afr[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) afr[p] = frag(Xs + p * XPL + toff + xaddr[ks][0], Xs + p * XPL + toff + xaddr[ks][1]);
+                    acc[t] = mfma_bf16x6(afr, bfr, acc[t]);
+                }
+            }
+        }
+    }
+    // gather the block's 9 x 16 x 32 tile in LDS (reusing the staging space) and add it with contiguous atomics
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(ctile);
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int tap = tg + 2 * t;
+        if (tap < 9)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[(tap * CIN + 4 * lq + r) * COUT + 16 * nt + li] = acc[t][r];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 9 * CIN * COUT; idx += 256) atomicAdd(dw + idx, red[idx]);
+}
+
 // dW[tap][ci][co] += sum_pixels x[b][oh+kh-1][ow+kw-1][ci] * dz[b][oh][ow][co],  CIN = 16, COUT = 32, all 9 taps per wave
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_wgrad_clip_kernel(const float *__restrict__ x, const float *__restrict__ dz,

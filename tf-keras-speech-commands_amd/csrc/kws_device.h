@@ -7,6 +7,7 @@ namespace kws {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+
 // v_mfma_f32_16x16x4_f32: exact fp32 (k-ordered fmaf chain), 64 lanes compute a 16x16 tile, K = 4.
 //   A operand: lane l holds A[row = l & 15][k = l >> 4]
 //   B operand: lane l holds B[k = l >> 4][col = l & 15]

@@ -517,144 +517,4 @@ __global__ __launch_bounds__(256, 4) void l1m_bwd_wgrad_kernel(const float *__re
 }
 
 
-// ---- single-pass backward of layer 1 ----------------------------------------------------------------------------------
-// dz = k1 (g - k2 - xhat k3) needs the batch means k2 = mean(g), k3 = mean(g xhat), which is why the two kernels above make
-// two passes over (features, da1).  The weight gradient is linear in dz, so it can be assembled from sums of ONE pass:
-//   dW[t][c] = sum_p dz[p][c] f[p+t] = k1 ( G[c][t] - k2 F[t] - k3 X[c][t] ),
-//   G[c][t] = sum_p g[p][c] f[p+t],   F[t] = sum_p f[p+t],
-//   X[c][t] = sum_p xhat[p][c] f[p+t] = inv ( sum_t' w[t'][c] R[t'][t] - mean F[t] ),   R[t'][t] = sum_p f[p+t'] f[p+t]
-// (z = sum_t' w[t'] f[p+t'] has no bias).  R and F do not depend on the channel.  l1m_bwd_fused_kernel collects sum g,
-// sum g xhat, G, R and F per block (float inside one clip, double across clips and blocks); l1_bwd_finalize_kernel sums the
-// block partials (one wave per row, fixed order: dW1 is deterministic, the two-pass form added it with float atomics) and
-// the last wave to finish evaluates the closed form in double.  Rows of the partial slab:
-constexpr int kL1RowS = 0, kL1RowSX = 16, kL1RowG = 32, kL1RowR = kL1RowG + 144, kL1RowF = kL1RowR + 81, kL1Rows = kL1RowF + 9;
-// row kL1Rows holds the arrival counter (zeroed by the fused kernel), row kL1Rows + 1 the 266 row sums
-
-__global__ __launch_bounds__(256, 4) void l1m_bwd_fused_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
-                                                             const float *__restrict__ da1, BnCoef k, int B, int H, int W,
-                                                             int clips_per_wave, double *__restrict__ partial)
-{
-    extern __shared__ float l1smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<unsigned *>(partial + (long)kL1Rows * kStatStride) = 0u;
-    L1Mma t;
-    t.init(wk, H, W, l1smem);
-    long first;
-    int count;
-    l1m_clips(B, clips_per_wave, first, count);
-    const float sc = k.scale[li], sh = k.shift[li], mean = k.mean[li], inv = k.inv[li];
-    // B side of the G / R products: this lane supplies f at tap li (< 9) of the element's pixel in window 4 tile + lq
-    const int tap = li < 9 ? li : 8, boff = (tap / 3) * t.WP + tap % 3;
-    const float bmask = li < 9 ? 1.f : 0.f;
-    // G and R are kept in double across the wave's clips in its own LDS row (register budget: 4 waves per SIMD)
-    __shared__ double red[4][kL1Rows];
-    for (int i = lane; i < kL1Rows; i += 64) red[wave][i] = 0.0;
-    double s = 0.0, sx = 0.0, dF = 0.0;
-    if (count > 0) t.fetch(feat, first);
-    for (int i = 0; i < count; ++i) {
-        const float *dsrc = da1 + (first + i) * t.nwin * 16 + li;
-        float dcur[kL1Group], dnxt[kL1Group];
-        auto fetch_da = [&](int t0, float (&dv)[kL1Group]) {
-#pragma unroll
-            for (int j = 0; j < kL1Group; ++j) dv[j] = 4 * (t0 + j) + lq < t.nwin ? dsrc[(4 * (t0 + j) + lq) * 16] : 0.f;
-        };
-        fetch_da(0, dnxt);
-        t.store();
-        if (i + 1 < count) t.fetch(feat, first + i + 1);
-        float fs = 0.f, fsx = 0.f, fF = 0.f;
-        f32x4 accG = {0.f, 0.f, 0.f, 0.f};                 // G[c = 4 lq + r][tap = li]
-        f32x4 accR = {0.f, 0.f, 0.f, 0.f};                 // R[tap' = 4 lq + r][tap = li]
-        for (int t0 = 0; t0 < t.ntile; t0 += kL1Group) {
-#pragma unroll
-            for (int j = 0; j < kL1Group; ++j) dcur[j] = dnxt[j];
-            if (t0 + kL1Group < t.ntile) fetch_da(t0 + kL1Group, dnxt);
-#pragma unroll
-            for (int j = 0; j < kL1Group; ++j) {
-                const int tile = t0 + j;
-                if (tile < t.ntile) {
-                    const int win = 4 * tile + lq;
-                    const bool ok = win < t.nwin;
-                    const f32x4 z = t.z(tile);
-                    int arg;
-                    float g;
-                    l1m_route(z, sc, sh, dcur[j], arg, g);       // da1 is 0 for windows past the clip, so g is
-                    const float za = arg == 0 ? z[0] : arg == 1 ? z[1] : arg == 2 ? z[2] : z[3];
-                    fs += g;
-                    fsx = fmaf(g, (za - mean) * inv, fsx);
-                    const int wq = ok ? win : 0, ph = wq / t.Wp, pw = wq - ph * t.Wp;
-                    const float *xb = t.xs + (2 * ph) * t.WP + 2 * pw + boff;
-                    const float vm = ok ? bmask : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = xb[(r >> 1) * t.WP + (r & 1)] * vm;
-                        accG = mfma16(r == arg ? g : 0.f, v, accG);
-                        accR = mfma16(v, v, accR);
-                        fF += v;
-                    }
-                }
-            }
-        }
-        s += (double)fs;
-        sx += (double)fsx;
-        dF += (double)fF;
-        if (li < 9) {                                       // each (row, tap) entry belongs to exactly one lane of the wave
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                red[wave][kL1RowG + (4 * lq + r) * 9 + li] += (double)accG[r];
-                if (4 * lq + r < 9) red[wave][kL1RowR + (4 * lq + r) * 9 + li] += (double)accR[r];
-            }
-        }
-    }
-    // block partials: over lq inside the wave where the sum runs over windows, then over the four waves through LDS
-    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-    sx += __shfl_xor(sx, 16, 64); sx += __shfl_xor(sx, 32, 64);
-    dF += __shfl_xor(dF, 16, 64); dF += __shfl_xor(dF, 32, 64);
-    if (lq == 0) {
-        red[wave][kL1RowS + li] = s;
-        red[wave][kL1RowSX + li] = sx;
-        if (li < 9) red[wave][kL1RowF + li] = dF;
-    }
-    __syncthreads();
-    for (int row = threadIdx.x; row < kL1Rows; row += 256)
-        partial[(long)row * kStatStride + blockIdx.x] = (red[0][row] + red[1][row]) + (red[2][row] + red[3][row]);
-}
-
-// grid = kL1Rows waves.  Wave `row` sums its row of block partials; the last wave to arrive (agent-scope counter) turns the
-// 266 sums into dgamma, dbeta, k2, k3 and the conv1 weight gradient dW[tap][c] (plain stores: nothing else adds to it).
-__global__ __launch_bounds__(64) void l1_bwd_finalize_kernel(double *__restrict__ partial, int nblk, double n_elems,
-                                                             const float *__restrict__ wk, const float *__restrict__ gamma,
-                                                             float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                             float *__restrict__ dw, BnCoef k)
-{
-    const int row = blockIdx.x, lane = threadIdx.x;
-    unsigned *counter = reinterpret_cast<unsigned *>(partial + (long)kL1Rows * kStatStride);
-    double *rowsum = partial + (long)(kL1Rows + 1) * kStatStride;
-    const double sum = wave_sum_partials(partial, 0, 1, row, nblk);        // C = 1: row index is the channel argument
-    unsigned ticket = 0;
-    if (lane == 0) {
-        __hip_atomic_store(&rowsum[row], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    ticket = __builtin_amdgcn_readfirstlane(ticket);
-    if (ticket != (unsigned)(kL1Rows - 1)) return;
-    __threadfence();
-    auto rs = [&](int r) { return __hip_atomic_load(&rowsum[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    for (int i = lane; i < 144; i += 64) {
-        const int c = i / 9, tp = i - 9 * c;
-        const double s = rs(kL1RowS + c), sx = rs(kL1RowSX + c), k2 = s / n_elems, k3 = sx / n_elems;
-        const double mean = (double)k.mean[c], inv = (double)k.inv[c];
-        double S = 0.0;
-        for (int u = 0; u < 9; ++u) S += (double)wk[u * 16 + c] * rs(kL1RowR + u * 9 + tp);
-        const double F = rs(kL1RowF + tp), X = inv * (S - mean * F);
-        dw[tp * 16 + c] = (float)((double)gamma[c] * inv * (rs(kL1RowG + c * 9 + tp) - k2 * F - k3 * X));
-        if (tp == 0) {
-            dbeta[c] = (float)s;
-            dgamma[c] = (float)sx;
-            k.k2[c] = (float)k2;
-            k.k3[c] = (float)k3;
-        }
-    }
-}
-
 }  // namespace kws

@@ -270,8 +270,10 @@ ConvGeom geom3x3(int B, int H, int W, int stride)
 }
 
 // ---- forward ------------------------------------------------------------------------------------------------
+// zero_grads (training, split precision): the gradient buffer of the backward pass that follows is cleared on the side
+// stream beside the weight split instead of on the main chain; *zeroed tells the caller whether that happened
 int cnn_forward(const kws_model *m, const float *feat, int B, const float *params, float *state, CnnWs &w, bool training,
-                uint64_t seed, hipStream_t s)
+                uint64_t seed, hipStream_t s, float *zero_grads = nullptr, bool *zeroed = nullptr)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};   // conv input sizes
@@ -286,6 +288,10 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         if (!s2) return fail(KWS_ERR_HIP, "cannot create the internal side stream");
         KWS_HIP_CHECK(hipEventRecord(sync_event(10), s));
         KWS_HIP_CHECK(hipStreamWaitEvent(s2, sync_event(10), 0));
+        if (zero_grads) {
+            KWS_HIP_CHECK(hipMemsetAsync(zero_grads, 0, sizeof(float) * (size_t)m->P, s2));
+            if (zeroed) *zeroed = true;
+        }
         if (int rc = split_weights(m, params, w, s2)) return rc;
         KWS_HIP_CHECK(hipEventRecord(sync_event(11), s2));
     } else if (bf16) {
@@ -397,7 +403,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
 
 // ---- backward -----------------------------------------------------------------------------------------------
 int cnn_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
-                 hipEvent_t bucket_event, hipStream_t s, float *stats)
+                 hipEvent_t bucket_event, hipStream_t s, float *stats, bool grads_zeroed = false)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
@@ -405,7 +411,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     const bool pool[4] = {true, true, false, true};
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
 
-    KWS_HIP_CHECK(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->P, s));
+    if (!grads_zeroed) KWS_HIP_CHECK(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->P, s));
     // The weight-gradient GEMM of a layer only READS (x, dz) and adds into grads; the data-gradient GEMM and the next
     // layer's BN backward do not depend on it.  Each of them alone leaves the MFMA pipe more than half idle, so wgrad runs
     // on the library's side stream (fork after dz is final, one join at the end) and shares the chip with the main chain.
@@ -428,8 +434,6 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     {
         ConvGeom g;
         g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
-        if (int rc = fork(0)) return rc;
-        launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s2);
         int nblk, rows;
         stat_grid(B, 128, nblk, rows);
         if (!head_bwd_fuses(m)) {
@@ -472,6 +476,11 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         if (l != 1)
             if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
+            // the dense weight gradient (ready since head_bwd) is forked together with conv4's: one event on the main chain
+            // instead of two (each costs the next main-chain kernel 6-8 us)
+            ConvGeom gd;
+            gd.B = B; gd.H = d.H4; gd.W = d.W4; gd.Ho = 1; gd.Wo = 1; gd.stride = 1; gd.pt = 0; gd.pl = 0; gd.KH = d.H4; gd.KW = d.W4;
+            launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, gd, s2);
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
             if (g_matrix_precision == 1) launch_wgrad_bf16<64, 128>(in, w.gz[3], dk, g, s2);
             else launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);
@@ -507,7 +516,13 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             } else
                 KWS_LAUNCH("conv_dgrad_clip<32,16>", (conv_dgrad_clip_kernel<32, true>), dim3(nblk_d), dim3(256), smd, s, w.gz[1], kern, w.da[0], B, H1, W1, bn);
             if (int rc = fork(1)) return rc;
-            KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);
+            if (g_matrix_precision == 1 && H1 * W1 <= 160) {
+                const size_t smwb = std::max((size_t)3 * 32 * (H1 + 2) * (W1 + 2) + (size_t)6 * 32 * (H1 * W1 + 1), sizeof(float) * 9 * 16 * 32);
+                static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel, 256, smwb);
+                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel, dim3(even_grid(cu_count() * std::min(occ, 3))), dim3(256), smwb, s2, in,
+                           w.gz[1], dk, B, H1, W1);
+            } else
+                KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);
         }
     }
     // layer 1: da1 -> (dgamma1, dbeta1, dW1) with conv1 recomputed; no z1-sized tensor is read or written
@@ -522,20 +537,13 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         const long M1 = (long)B * d.H0 * d.W0;
         BnCoef k1 = coef_of(w.coef[0], 16);
         const float *kern1 = params + m->o_k[0];
-        static const bool two_pass = getenv("KWS_L1_TWO_PASS") != nullptr;     // A/B switch (measurement only)
-        if (l1m && two_pass) {
+        if (l1m) {
             KWS_LAUNCH("l1m_bwd_reduce_kernel", l1m_bwd_reduce_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
                        cpw, w.partial);
             KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(64), 0, s, w.partial, nbm, M1, 16,
                        params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], k1);
             KWS_LAUNCH("l1m_bwd_wgrad_kernel", l1m_bwd_wgrad_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
                        grads + m->o_k[0], B, d.H0, d.W0, cpw);
-        } else if (l1m) {
-            // single pass: every sum the closed form of dW1 needs (kws_layer1.h), then one small finalize launch
-            KWS_LAUNCH("l1m_bwd_fused_kernel", l1m_bwd_fused_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0, cpw,
-                       w.partial);
-            KWS_LAUNCH("l1_bwd_finalize_kernel", l1_bwd_finalize_kernel, dim3(kL1Rows), dim3(64), 0, s, w.partial, nbm, (double)M1, kern1,
-                       params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], grads + m->o_k[0], k1);
         } else {
             KWS_LAUNCH("l1_bwd_reduce_kernel", l1_bwd_reduce_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
                        cpb, w.partial);
@@ -886,8 +894,9 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool lite = m->kind == KWS_SIMPLE_CNN_LITE;
+    bool grads_zeroed = false;     // cleared beside the weight split (the main chain joins that branch before conv3)
     rc = lite ? lite_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s)
-              : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s);
+              : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s, a->grads, &grads_zeroed);
     if (rc) return rc;
     // Keras reduces the per-sample losses with a batch mean (train.py:75-77): d(mean)/d(logits) carries 1/B
     // simple_cnn: the head's backward kernel also sums the per-sample losses (no separate loss_reduce launch)
@@ -898,7 +907,7 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
     return lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
                 : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s,
-                               fuse_stats ? a->stats : nullptr);
+                               fuse_stats ? a->stats : nullptr, grads_zeroed);
 }
 
 int kws_set_matrix_precision(int mode)

@@ -434,6 +434,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     {
         ConvGeom g;
         g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
+        // its own fork, although every event costs the main chain 6-8 us: started later, together with conv4's weight
+        // gradient, the step was 2 % slower (same-box A/B)
+        if (int rc = fork(0)) return rc;
+        launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s2);
         int nblk, rows;
         stat_grid(B, 128, nblk, rows);
         if (!head_bwd_fuses(m)) {
@@ -476,11 +480,6 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         if (l != 1)
             if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
-            // the dense weight gradient (ready since head_bwd) is forked together with conv4's: one event on the main chain
-            // instead of two (each costs the next main-chain kernel 6-8 us)
-            ConvGeom gd;
-            gd.B = B; gd.H = d.H4; gd.W = d.W4; gd.Ho = 1; gd.Wo = 1; gd.stride = 1; gd.pt = 0; gd.pl = 0; gd.KH = d.H4; gd.KW = d.W4;
-            launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, gd, s2);
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
             if (g_matrix_precision == 1) launch_wgrad_bf16<64, 128>(in, w.gz[3], dk, g, s2);
             else launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);

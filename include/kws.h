@@ -198,6 +198,16 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
 enum { KWS_MATRIX_FP32 = 0, KWS_MATRIX_BF16X6 = 1 };
 int kws_set_matrix_precision(int mode);
 int kws_get_matrix_precision(void);
+/* Precision of simple_cnn_lite INFERENCE (kws_model_forward; BASELINE configs[4] asks fp16).  Library-wide switch.
+ *   KWS_INFER_FP32 (default): fp32 activations and products.
+ *   KWS_INFER_FP16: the activations between stages and every matrix operand are fp16, all accumulation (depthwise taps,
+ *                   matrix products, bias / BatchNorm affine, softmax) fp32; the network behind the second pooling stage
+ *                   runs as ONE kernel with its fp16 weights in LDS.  Needs the default geometry family (pooled maps up to
+ *                   7 x 5 / 4 x 3) and at most 48 classes, otherwise kws_model_forward returns KWS_ERR_UNSUPPORTED.
+ * Other model kinds ignore the switch (classifier/models/cnn.py:77-141 is the topology it applies to). */
+enum { KWS_INFER_FP32 = 0, KWS_INFER_FP16 = 1 };
+int kws_set_inference_precision(int mode);
+int kws_get_inference_precision(void);
 
 /* offset (in floats) that splits `grads` into {late bucket [0, split), early bucket [split, param_count)} */
 int64_t kws_model_grad_split(const kws_model *m);

@@ -259,6 +259,60 @@ def test_lite_inference_forward(torch, B):
     np.testing.assert_array_equal(am.cpu().numpy(), want.argmax(-1))
 
 
+@pytest.mark.parametrize("B,C", [(1, 36), (33, 36), (100, 5), (4096, 36)])
+def test_lite_inference_forward_fp16(torch, B, C):
+    """BASELINE configs[4]: simple_cnn_lite inference with fp16 activations / matrix operands and fp32 accumulation
+    (kws_set_inference_precision).  Tolerance: the north star's own 1e-3 on the probabilities against the float64 oracle
+    (measured 4e-5: fp16 operands, fp32 accumulation) and against the fp32 device path; the class index is exact wherever
+    the oracle's two best classes are more than 2e-3 apart (twice the tolerance) and agrees on at least 99 % of the clips."""
+    import kws_amd.lib as L
+    om, dm = build("simple_cnn_lite", C)
+    x = features(B, 29 + B)
+    xd = torch.from_numpy(x).cuda()
+    p32, a32 = dm.forward(xd)
+    p32 = p32.cpu().numpy()
+    assert L.get_inference_precision() == L.INFER_FP32
+    L.set_inference_precision(L.INFER_FP16)
+    try:
+        assert L.get_inference_precision() == L.INFER_FP16
+        p16, a16 = dm.forward(xd)
+        p16b, _ = dm.forward(xd)
+        with pytest.raises(Exception):
+            L.set_inference_precision(9)
+    finally:
+        L.set_inference_precision(L.INFER_FP32)
+    p16, a16 = p16.cpu().numpy(), a16.cpu().numpy()
+    np.testing.assert_array_equal(p16, p16b.cpu().numpy())                  # deterministic
+    want = om.predict(x.astype(np.float64))
+    np.testing.assert_allclose(p16.sum(-1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(p16, want, atol=1e-3, rtol=0)
+    np.testing.assert_allclose(p16, p32, atol=1e-3, rtol=0)
+    assert np.abs(p16 - p32).max() > 0                                       # the fp16 path really ran
+    top2 = np.sort(want, axis=-1)[:, -2:]
+    err = float(np.abs(p16 - want).max())
+    print("fp16 lite inference: max |dp| vs float64 oracle %.2e, vs fp32 device path %.2e" % (err, float(np.abs(p16 - p32).max())))
+    clear = (top2[:, 1] - top2[:, 0]) > 2e-3                               # beyond twice the probability tolerance
+    np.testing.assert_array_equal(a16[clear], want.argmax(-1)[clear])
+    assert (a16 == want.argmax(-1)).mean() >= 0.99
+
+
+def test_lite_fp16_rejects_unsupported_geometry(torch):
+    """fp16 inference covers the default geometry family; elsewhere the call reports KWS_ERR_UNSUPPORTED (no silent fp32)."""
+    import kws_amd.lib as L
+    from kws_amd.model import DeviceModel, ModelSpec
+    from oracle import model_oracle as mo
+    spec = ModelSpec("simple_cnn_lite", 36, 62, 21)
+    dm = DeviceModel(spec)
+    x = torch.zeros((2, 62, 21), dtype=torch.float32, device="cuda")
+    dm.forward(x)                                                            # fp32 is fine
+    L.set_inference_precision(L.INFER_FP16)
+    try:
+        with pytest.raises(Exception, match="fp16 inference"):
+            dm.forward(x)
+    finally:
+        L.set_inference_precision(L.INFER_FP32)
+
+
 @pytest.mark.parametrize("weighted,seed", [(False, 0), (True, 0x77AA55)])
 def test_lite_train_forward_backward(torch, weighted, seed):
     from oracle import model_oracle as mo

@@ -165,8 +165,9 @@ __host__ __device__ inline int lite_front_floats(int H, int W)
     return ((H1 + 2) * (W1 + 2) * 16 + (a > b ? a : b) + 3) & ~3;
 }
 
+// a2h != nullptr: the pooled activation is written as fp16 there instead (fp16 inference, kws_lite_f16.h)
 __global__ __launch_bounds__(64) void lite_front_infer_kernel(const float *__restrict__ feat, LiteFrontArgs k, float *__restrict__ a2,
-                                                               int B, int H, int W, int clips_per_wave)
+                                                               int B, int H, int W, int clips_per_wave, _Float16 *__restrict__ a2h = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     const int lane = threadIdx.x, li = lane & 15, lq = lane >> 4;
@@ -264,8 +265,14 @@ __global__ __launch_bounds__(64) void lite_front_infer_kernel(const float *__res
                     m0 = fmaxf(m0, fmaf(acc0[r] + b2a, sc2a, sh2a));
                     m1 = fmaxf(m1, fmaf(acc1[r] + b2b, sc2b, sh2b));
                 }
-                out[w * 32 + li] = relu6f(m0);
-                out[w * 32 + 16 + li] = relu6f(m1);
+                if (a2h) {
+                    _Float16 *outh = a2h + (first + ci) * n2 * 32;
+                    outh[w * 32 + li] = (_Float16)relu6f(m0);
+                    outh[w * 32 + 16 + li] = (_Float16)relu6f(m1);
+                } else {
+                    out[w * 32 + li] = relu6f(m0);
+                    out[w * 32 + 16 + li] = relu6f(m1);
+                }
             }
         }
     }

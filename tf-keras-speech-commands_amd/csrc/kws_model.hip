@@ -14,6 +14,7 @@
 #include "kws_layers.h"
 #include "kws_layer1.h"
 #include "kws_lite.h"
+#include "kws_lite_f16.h"
 
 using namespace kws;
 
@@ -567,6 +568,48 @@ ConvGeom geom1x1(int B, int H, int W)
     return g;
 }
 
+// Storage / matrix-operand precision of simple_cnn_lite INFERENCE (kws_set_inference_precision): 0 = fp32, 1 = fp16
+static int g_infer_precision = 0;
+
+// fp16 inference (kws_lite_f16.h): front kernel with fp16 output, then ONE kernel from a2 to the probabilities.
+// The fp16 weight blob lives at the head of the (otherwise unused in inference) double partial slab.
+static int lite_forward_f16(const kws_model *m, const float *feat, int B, const float *params, const float *state, CnnWs &w, float *probs,
+                            int32_t *argmax, hipStream_t s)
+{
+    const CnnDims &d = m->d;
+    const bool front_ok = d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * 12 && d.H2 >= 1 && d.W2 >= 1;
+    if (!front_ok || d.H2 * d.W2 > kF16MaxN2 || d.H3 * d.W3 > kF16MaxP3 || d.H4 < 1 || d.W4 < 1 || m->C > kF16HeadCols || d.flat > kWdRow)
+        return fail(KWS_ERR_UNSUPPORTED, "fp16 inference of simple_cnn_lite needs a feature map up to about 30 x 20 and at most %d classes "
+                                         "(got %d x %d, %d classes): use KWS_INFER_FP32", kF16HeadCols, d.H0, d.W0, m->C);
+    if (int rc = infer_coefs(m, params, state, w, s)) return rc;
+    _Float16 *blob = reinterpret_cast<_Float16 *>(w.partial);
+    KWS_LAUNCH("lite_f16_prepare_kernel", lite_f16_prepare_kernel, dim3(32), dim3(256), 0, s, params + m->o_pwk[2], params + m->o_pwk[3],
+               params + m->o_dk, params + m->o_hk, m->C, d.flat, blob);
+    BnCoef k0 = coef_of(w.coef[0], 16), k1 = coef_of(w.coef[1], 32), k2 = coef_of(w.coef[2], 64), k3 = coef_of(w.coef[3], 128);
+    const LiteFrontArgs fa = {params + m->o_dwk[0], params + m->o_pwk[0], params + m->o_pwb[0], k0.scale, k0.shift,
+                              params + m->o_dwk[1], params + m->o_pwk[1], params + m->o_pwb[1], k1.scale, k1.shift};
+    const size_t sm = sizeof(float) * (size_t)lite_front_floats(d.H0, d.W0);
+    const int waves = cu_count() * std::max(1, std::min(8, (int)(160 * 1024 / sm)));
+    const int cpw = std::max(1, (B + waves - 1) / waves), nblk = (B + cpw - 1) / cpw;
+    _Float16 *a2h = reinterpret_cast<_Float16 *>(w.a[1]);
+    KWS_LAUNCH("lite_front_infer_kernel", lite_front_infer_kernel, dim3(nblk), dim3(64), sm, s, feat, fa, w.a[1], B, d.H0, d.W0, cpw, a2h);
+    LiteF16Args a;
+    a.dwk3 = params + m->o_dwk[2]; a.pwb3 = params + m->o_pwb[2]; a.sc3 = k2.scale; a.sh3 = k2.shift;
+    a.dwk4 = params + m->o_dwk[3]; a.pwb4 = params + m->o_pwb[3]; a.sc4 = k3.scale; a.sh4 = k3.shift;
+    a.db = params + m->o_db; a.hb = params + m->o_hb; a.blob = blob;
+    a.C = m->C; a.H2 = d.H2; a.W2 = d.W2; a.H3 = d.H3; a.W3 = d.W3;
+    a.pt3 = same_pad_before(d.H2, 3, 2); a.pl3 = same_pad_before(d.W2, 3, 2); a.H4 = d.H4; a.W4 = d.W4;
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lite_back_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
+        return true;
+    }();
+    (void)attr;
+    const int ntile = (B + kF16Clips - 1) / kF16Clips;
+    KWS_LAUNCH("lite_back_f16_kernel", lite_back_f16_kernel, dim3(std::min(ntile, cu_count())), dim3(256), (size_t)kF16LdsBytes, s, a2h, a, B, probs, argmax);
+    KWS_LAUNCH_CHECK("simple_cnn_lite fp16 forward");
+    return KWS_OK;
+}
+
 int lite_forward(const kws_model *m, const float *feat, int B, const float *params, float *state, CnnWs &w, bool training,
                  uint64_t seed, hipStream_t s)
 {
@@ -877,6 +920,8 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
     int rc = check_ws(m, B, false, ws, ws_bytes, w);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (m->kind == KWS_SIMPLE_CNN_LITE && g_infer_precision == KWS_INFER_FP16)
+        return lite_forward_f16(m, feat, B, params, state, w, probs, argmax, s);
     rc = m->kind == KWS_SIMPLE_CNN_LITE ? lite_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s)
                                         : cnn_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s);
     if (rc) return rc;
@@ -917,6 +962,14 @@ int kws_set_matrix_precision(int mode)
 }
 
 int kws_get_matrix_precision(void) { return g_matrix_precision; }
+
+int kws_set_inference_precision(int mode)
+{
+    if (mode != KWS_INFER_FP32 && mode != KWS_INFER_FP16) return fail(KWS_ERR_INVALID, "unknown inference precision %d", mode);
+    g_infer_precision = mode;
+    return KWS_OK;
+}
+int kws_get_inference_precision(void) { return g_infer_precision; }
 
 int64_t kws_model_grad_split(const kws_model *m)
 {

@@ -8,11 +8,14 @@ from . import lib as _l
 class InferenceSession(object):
     """Static-shape streaming inference: copy (or write) a batch into `self.wav`, call run(), read `self.probs`/`argmax`."""
 
-    def __init__(self, device_model, featurizer, batch, samples=None, wav_dtype=None, use_graph=True):
+    def __init__(self, device_model, featurizer, batch, samples=None, wav_dtype=None, use_graph=True, fp16=False):
         import torch
         if not torch.cuda.is_available():
             raise _l.KwsError(-3, "no HIP device: inference has no CPU fallback")
         self.dm, self.feat, self.batch = device_model, featurizer, int(batch)
+        # fp16=True: simple_cnn_lite forward with fp16 activations / matrix operands, fp32 accumulation (BASELINE configs[4]);
+        # the library switch is read when the kernels are enqueued, so it is set around every eager run and the capture
+        self.precision = _l.INFER_FP16 if fp16 else _l.INFER_FP32
         g = featurizer.geometry
         samples = int(samples or g["max_samples"])
         wav_dtype = wav_dtype or torch.float32
@@ -31,7 +34,12 @@ class InferenceSession(object):
 
     def _eager(self):
         self.feat(self.wav, out=self.features)
-        self.probs, self.argmax = self.dm.forward(self.features)
+        before = _l.get_inference_precision()
+        _l.set_inference_precision(self.precision)
+        try:
+            self.probs, self.argmax = self.dm.forward(self.features)
+        finally:
+            _l.set_inference_precision(before)
 
     def run(self):
         if self._graph is not None:

@@ -104,6 +104,8 @@ def get_lib():
     L.kws_stream_postprocess.argtypes = [vp, vp, i32, i32, i32, f64, i32, i32, vp, vp, vp, vp, vp]
     L.kws_set_matrix_precision.argtypes = [i32]
     L.kws_get_matrix_precision.restype = i32
+    L.kws_set_inference_precision.argtypes = [i32]
+    L.kws_get_inference_precision.restype = i32
     L.kws_prof_enable.argtypes = [i32]
     L.kws_prof_report.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.kws_prof_report.restype = i64
@@ -125,6 +127,7 @@ def device_count():
 
 
 MATRIX_FP32, MATRIX_BF16X6 = 0, 1
+INFER_FP32, INFER_FP16 = 0, 1
 
 
 def set_matrix_precision(mode):
@@ -134,6 +137,16 @@ def set_matrix_precision(mode):
 
 def get_matrix_precision():
     return get_lib().kws_get_matrix_precision()
+
+
+def set_inference_precision(mode):
+    """INFER_FP32 (default) or INFER_FP16: simple_cnn_lite inference with fp16 activations and matrix operands, fp32
+    accumulation (BASELINE configs[4]); other model kinds ignore the switch."""
+    check(get_lib().kws_set_inference_precision(int(mode)))
+
+
+def get_inference_precision():
+    return get_lib().kws_get_inference_precision()
 
 
 def prof_enable(on=True):

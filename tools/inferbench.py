@@ -48,3 +48,32 @@ for mt, B in (("simple_cnn_lite", 16384), ("simple_cnn", 4096)):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     print("%-16s B=%5d PCM16 in, hipGraph  %.3f ms  %.2f Mclips/s  (%.1f%% of the 8 TB/s roofline at 32144 B/clip)" % (mt, B, ms, B / ms / 1e3, B / ms / 1e3 * 32144 / 8e6 * 100))
+# BASELINE configs[4]: simple_cnn_lite streaming inference, batch 16384, hipGraph-captured featurize + forward, fp16
+# (fp16 activations / matrix operands behind the featurizer, fp32 accumulation; kws_set_inference_precision)
+spec = ModelSpec("simple_cnn_lite", 36, 30, 20); dm = DeviceModel(spec); dm.set_weights(init_weights(spec, 0))
+for wd, scale, nbytes in ((torch.float32, 0.1, 64144), (torch.int16, 3000, 32144)):
+    res = {}
+    for fp16 in (False, True):
+        s = InferenceSession(dm, feat, 16384, wav_dtype=wd, use_graph=True, fp16=fp16)
+        torch.manual_seed(0)
+        s.wav.copy_((scale * torch.randn((16384, 16000), device="cuda")).to(wd))
+        for _ in range(3): s.run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20): s.run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        res[fp16] = (s.probs.clone(), s.argmax.clone())
+        print("simple_cnn_lite  B=16384 %s in, hipGraph, %s  %.3f ms  %.2f Mclips/s  (%.1f%% of the 8 TB/s roofline at %d B/clip)" % (
+            "PCM16" if wd == torch.int16 else "f32", "fp16" if fp16 else "fp32", ms, 16384 / ms / 1e3, 16384 / ms / 1e3 * nbytes / 8e6 * 100, nbytes))
+    print("   fp16 vs fp32: max |dp| %.2e, argmax agreement %.4f" % (float((res[True][0] - res[False][0]).abs().max()),
+                                                                  float((res[True][1] == res[False][1]).float().mean())))
+L.prof_enable(True)
+s = InferenceSession(dm, feat, 16384, use_graph=False, fp16=True)
+s.wav.copy_(0.1 * torch.randn((16384, 16000), device="cuda"))
+L.prof_report()
+for _ in range(10): s.run()
+rep = L.prof_report(); L.prof_enable(False)
+for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"]):
+    print("   %-34s %.4f ms" % (k, v["total_ms"] / 10))

@@ -1146,6 +1146,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_clip_bf16_kernel(const float 
 // over g, where the weight-gradient kernel picks it up.
 struct BnBwdArgs {
     const float *z, *gamma, *mean, *inv, *k2, *k3;
+    // compact form of g (bn_bwd_reduce_pool_kernel<true>): routed value per (pool window, channel) and the element it goes to;
+    // gw == nullptr: g is read full-size from the dz buffer
+    const float *gw = nullptr;
+    const unsigned char *arg = nullptr;
 };
 template <int CR, bool BN>
 __global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(float *__restrict__ dz, const float *__restrict__ wgt,
@@ -1255,7 +1259,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(float *__restrict_
 // consecutive pixels fill the 64 banks.  The 9 x 3 weight fragments W[tap][n = li][8 lq ..] stay in registers (256-register
 // budget, two blocks per CU).  The ten pixel tiles of a 15 x 10 map do not divide over four waves, so the tile a wave
 // starts with rotates from clip to clip and every SIMD sees the same load over time.
-template <bool BN>
+// COMPACT: g arrives as (routed value per pool window, element index) -- bn.gw / bn.arg -- and is rebuilt while staging
+template <bool BN, bool COMPACT = false>
 __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__restrict__ dz, const float *__restrict__ wgt,
                                                                        float *__restrict__ dx, int B, int H, int W, BnBwdArgs bn)
 {
@@ -1281,6 +1286,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__r
     constexpr int PF = 5;                                         // float4 held per thread for the next clip (<= 1280 per clip)
     const int nf4 = HW * F4;
     f32x4 pf[PF], pz[PF];
+    unsigned pa[PF];                                              // COMPACT: the four element indices of the float4's window
     float gi[4], mean[4], inv[4], k2[4], k3[4];                   // BN coefficients of this thread's 4 channels (c4 = threadIdx.x % F4)
     if (BN) {
 #pragma unroll
@@ -1295,13 +1301,32 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__r
         for (int e = 0; e < 4; ++e) d[e] = gi[e] * (g[e] - k2[e] - (zv[e] - mean[e]) * inv[e] * k3[e]);
         return d;
     };
+    // compact g: window (float4 index inside the clip's window table) and element of each float4 this thread stages; -1 =
+    // the pixel lies outside every pool window (odd H or W) and its g is zero
+    const int Wp = W / 2, nwin = (H / 2) * Wp;
+    int cq[PF], ce[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int i = threadIdx.x + 256 * j, pix = i / F4, c4 = i % F4, y = pix / W, xx = pix - y * W;
+        const bool in = i < nf4 && y < 2 * (H / 2) && xx < 2 * Wp;
+        cq[j] = in ? ((y >> 1) * Wp + (xx >> 1)) * F4 + c4 : -1;
+        ce[j] = (y & 1) * 2 + (xx & 1);
+    }
     auto prefetch = [&](int b) {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(dz + (long)b * HW * CR);
         const f32x4 *zs = reinterpret_cast<const f32x4 *>(bn.z + (long)b * HW * CR);
+        const f32x4 *gws = reinterpret_cast<const f32x4 *>(bn.gw) + (long)b * nwin * F4;
+        const unsigned *ars = reinterpret_cast<const unsigned *>(bn.arg) + (long)b * nwin * F4;
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             const int i = threadIdx.x + 256 * j;
-            pf[j] = i < nf4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (COMPACT) {                                        // raw loads only: the select happens when the clip is staged
+                const int q = cq[j] >= 0 ? cq[j] : 0;
+                pf[j] = gws[q];
+                pa[j] = ars[q];
+            } else {
+                pf[j] = i < nf4 ? src[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
             if (BN) pz[j] = i < nf4 ? zs[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -1324,6 +1349,10 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__r
             const int i = threadIdx.x + 256 * j;
             if (i < nf4) {
                 f32x4 v = pf[j];
+                if (COMPACT) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (cq[j] >= 0 && (int)((pa[j] >> (8 * e)) & 0xFFu) == ce[j]) ? v[e] : 0.f;
+                }
                 if (BN) { v = bn_apply(v, pz[j]); dst[i] = v; }
                 stage(i, v);
             }

@@ -238,10 +238,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float *__restr
 // Pooled layers, one thread per (pool window, channel): the four elements of the window are read once, the gradient goes
 // to the first arg-max (if its ReLU6 is live), the other three and the pixels outside every window (odd H or W) get g = 0.
 // Same outputs as bn_bwd_reduce_kernel<true> (gz and the double partial sums) at a quarter of the loads.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const float *__restrict__ z, const float *__restrict__ da, BnCoef k,
+// COMPACT: g is non-zero at ONE element per window, so instead of a z-sized gz the kernel leaves the routed, gated value
+// per (window, channel) in place of da and the element index (0..3) as a byte in `arg`; the consumer (conv2's clip data
+// gradient) rebuilds g while it stages.  Pixels outside every window have g = 0 by construction.
+template <bool COMPACT = false>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const float *__restrict__ z, float *da, BnCoef k,
                                                                   float *__restrict__ gz, int B, int H, int W, int C,
                                                                   int wins_per_block, double *__restrict__ partial,
-                                                                  float drop_rate, uint32_t seed_lo, uint32_t seed_hi)
+                                                                  float drop_rate, uint32_t seed_lo, uint32_t seed_hi,
+                                                                  unsigned char *__restrict__ arg_out = nullptr)
 {
     const int c = threadIdx.x % C, r = threadIdx.x / C, R = 256 / C;
     const int Hp = H / 2, Wp = W / 2;
@@ -265,14 +270,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const float *__
         const float ya = arg == 0 ? y[0] : arg == 1 ? y[1] : arg == 2 ? y[2] : y[3];
         const float za = arg == 0 ? zv[0] : arg == 1 ? zv[1] : arg == 2 ? zv[2] : zv[3];
         g = (ya > 0.f && ya < 6.f) ? g : 0.f;
+        if (COMPACT) {
+            da[q * C + c] = g;
+            arg_out[q * C + c] = (unsigned char)arg;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gz[off[j]] = j == arg ? g : 0.f;
+            for (int j = 0; j < 4; ++j) gz[off[j]] = j == arg ? g : 0.f;
+        }
         s += (double)g;
         sx += (double)g * (double)((za - mean) * inv);
     }
     // pixels outside every window: g = 0 (only when H or W is odd)
     const int nbh = H - 2 * Hp, nbw = W - 2 * Wp;
-    if (nbh || nbw) {
+    if (!COMPACT && (nbh || nbw)) {
         const long per = (long)nbh * W + (long)nbw * 2 * Hp, NB = (long)B * per;
         for (long q = (long)blockIdx.x * (256 / C) + r; q < NB; q += (long)gridDim.x * (256 / C)) {
             const int b = (int)(q / per), e = (int)(q % per);

@@ -457,11 +457,20 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         stat_grid(M, C, nblk, rows);
         // the forward applied dropout to a[3]; its mask is re-derived from the seed here
         const float rate = (l == 3 && seed != 0) ? 0.5f : 0.f;
+        // conv2 (split precision): g stays compact -- the routed value per pool window in place of da[1], the element index as
+        // a byte in the (dead by now) da[2] buffer -- and the clip data gradient rebuilds it while staging: 54 MB less to
+        // write here and 54 MB less to read there at B = 4096
+        const bool compact_g = l == 1 && g_matrix_precision == 1 && Hz[1] * Wz[1] * 8 <= 1280 &&
+                               (size_t)(Hz[1] / 2) * (Wz[1] / 2) * 32 <= sizeof(float) * (size_t)d.H3 * d.W3 * 64;
         if (pool[l]) {
             const long NW = (long)B * (Hz[l] / 2) * (Wz[l] / 2);       // one thread per (pool window, channel)
             stat_grid(NW, C, nblk, rows);
-            KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_pool_kernel, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B,
-                       Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);
+            if (compact_g)
+                KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_pool_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], w.da[1], k,
+                           w.gz[l], B, Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi, reinterpret_cast<unsigned char *>(w.da[2]));
+            else
+                KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_pool_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l],
+                           const_cast<float *>(da), k, w.gz[l], B, Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);
         } else
             KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
                        rows, w.partial, rate, slo, shi);
@@ -507,12 +516,17 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const size_t smw2 = std::max(smw, sizeof(float) * (size_t)(1024 + 16 * 32));
             // dgrad forms dz2 from (g, z2) while staging and leaves it in gz[1]; wgrad then overlaps with layer 1's kernels
             const size_t smd = sizeof(float) * (size_t)(H1 + 2) * (W1 + 2) * (32 + 4);
-            const BnBwdArgs bn = {w.z[1], params + m->o_g[1], k.mean, k.inv, k.k2, k.k3};
+            BnBwdArgs bn = {w.z[1], params + m->o_g[1], k.mean, k.inv, k.k2, k.k3};
+            if (compact_g) { bn.gw = w.da[1]; bn.arg = reinterpret_cast<const unsigned char *>(w.da[2]); }
             if (g_matrix_precision == 1) {
                 // split-precision form: 2 blocks per CU by registers (the weight fragments of all nine taps stay in them)
                 const size_t smdb = (size_t)12 * 16 * (H1 + 2) * (W1 + 2);
-                KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s, w.gz[1],
-                           kern, w.da[0], B, H1, W1, bn);
+                if (compact_g)
+                    KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s,
+                               w.gz[1], kern, w.da[0], B, H1, W1, bn);
+                else
+                    KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, false>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s,
+                               w.gz[1], kern, w.da[0], B, H1, W1, bn);
             } else
                 KWS_LAUNCH("conv_dgrad_clip<32,16>", (conv_dgrad_clip_kernel<32, true>), dim3(nblk_d), dim3(256), smd, s, w.gz[1], kern, w.da[0], B, H1, W1, bn);
             if (int rc = fork(1)) return rc;

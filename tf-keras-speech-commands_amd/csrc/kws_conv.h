@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
                                                          float *__restrict__ dst, ConvGeom g, double *__restrict__ partial = nullptr,
                                                          int partial_stride = 0, const float *__restrict__ shift = nullptr)
 {
-    constexpr int KC = 32, SK = 40;            // chunk depth and LDS row stride in bf16 units
+    // chunk depth and LDS row stride in bf16 units.  96-byte rows: ds_read_b128 serves the lane groups {0-3,12-15,20-27}, ... (not
+    // 16 consecutive lanes), and fragment reads at (row li, 16-byte piece lq) are conflict-free for strides of 16 B x (2 mod 4);
+    // the 80-byte rows used before cost two LDS cycles per group (PMC: more conflict cycles than LDS instruction cycles)
+    constexpr int KC = 32, SK = 48;
     constexpr int BM = 32 * RT;                // rows per block: RT row tiles per wave, 2 waves along M
     constexpr int NT = CO / 16, CT = NT / 2;   // column tiles per wave (2 waves along N)
     constexpr int CPT = CR / KC;
@@ -1018,7 +1021,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_clip_bf16_kernel(const float 
     extern __shared__ __attribute__((aligned(16))) unsigned char ctile[];   // [3 planes][2 halves][(H+2)(W+2)][8 bf16], zero halo
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lq = lane >> 4;
     const int nt = wave & 1, tpar = wave >> 1;
-    const int HP = H + 2, WP = W + 2, HW = H * W, NPIX = HP * WP;
+    // halo pixels per (plane, half), rounded to 16: the 16-byte pieces of the two channel halves then sit a multiple of 256 B
+    // apart and the ds_read_b128 lane groups (which mix lq = 0/1 lanes) see 16 different bank quads
+    const int HP = H + 2, WP = W + 2, HW = H * W, NPIX = (HP * WP + 15) & ~15;
     const int W2 = W / 2, n2 = (H / 2) * W2;                       // pool windows (POOLED)
     const int ntile = POOLED ? (n2 + 3) / 4 : (HW + 15) / 16;
     for (int i = threadIdx.x; i < 6 * NPIX * 4; i += 256) reinterpret_cast<unsigned *>(ctile)[i] = 0u;
@@ -1267,7 +1272,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__r
     constexpr int CR = 32, CO = 16, F4 = CR / 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char ctile[];   // [3 planes][4 quarters][(H+2)(W+2)][8 bf16], zero halo
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lq = lane >> 4;
-    const int HP = H + 2, WP = W + 2, HW = H * W, NPIX = HP * WP, ntile = (HW + 15) / 16;
+    const int HP = H + 2, WP = W + 2, HW = H * W, NPIX = (HP * WP + 15) & ~15, ntile = (HW + 15) / 16;   // rounded: see the forward kernel
     for (int i = threadIdx.x; i < 12 * NPIX * 4; i += 256) reinterpret_cast<unsigned *>(ctile)[i] = 0u;
 
     bf16x8 wf[9][3];

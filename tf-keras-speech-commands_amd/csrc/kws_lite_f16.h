@@ -12,7 +12,8 @@
 // 36 KB (+ 64 KB for Dense, streamed from L2), so they sit in LDS beside two ping-pong activation regions and the whole
 // back end of the network runs without touching HBM between the a2 read and the probability write.  Matrix products run
 // on v_mfma_f32_16x16x32_f16; LDS rows are padded so that the 16-byte fragment reads of 16 consecutive rows fall into
-// different banks (row strides of 20, 36, 68 and 132 words).
+// different banks: ds_read_b128 serves the lane groups {0-3,12-15,20-27}, ..., and reads at (row li, 16-byte piece lq) are
+// conflict-free for row strides of 16 B x (2 mod 4) -- 96, 160, 288 and 544 bytes here.
 #pragma once
 #include <hip/hip_fp16.h>
 
@@ -27,7 +28,7 @@ constexpr int kF16Clips = 16;                    // clips per block tile
 constexpr int kF16MaxP3 = 12, kF16MaxN2 = 35;    // geometry limits of the fused back end (default geometry: 4x3 and 7x5)
 constexpr int kF16HeadCols = 48;                 // head columns in LDS (C <= 48)
 // fp16 weight blob (halfs), written by lite_f16_prepare_kernel: transposed [n][k] rows, padded by 8 halfs where staged in LDS
-constexpr int kW3Row = 40, kW4Row = 72, kW2Row = 136, kWdRow = 256;
+constexpr int kW3Row = 48, kW4Row = 80, kW2Row = 144, kWdRow = 256;
 constexpr int kBlobW3 = 0, kBlobW4 = kBlobW3 + 64 * kW3Row, kBlobW2 = kBlobW4 + 128 * kW4Row,
               kBlobLds = kBlobW2 + kF16HeadCols * kW2Row,      // the part of the blob a block copies into LDS
               kBlobWd = kBlobLds, kBlobHalfs = kBlobWd + 128 * kWdRow;
@@ -67,8 +68,8 @@ __global__ __launch_bounds__(256) void lite_f16_prepare_kernel(const float *__re
 __device__ __forceinline__ f32x4 mfma_f16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 // LDS carve (bytes): two activation regions that alternate, then the weights
-constexpr int kR1Bytes = 192 * 272;              // A2 (16 x 35 x 64 B) | A3 (192 x 144 B) | Z4 (192 x 272 B) | D1 + logits
-constexpr int kR2Bytes = 192 * 144;              // D3 (192 x 80 B) | D4 (192 x 144 B) | A4 (16 x 528 B)
+constexpr int kR1Bytes = 192 * 288;              // A2 (16 x 35 x 64 B) | A3 (192 x 160 B) | Z4 (192 x 288 B) | D1 + logits
+constexpr int kR2Bytes = 192 * 160;              // D3 (192 x 96 B) | D4 (192 x 160 B) | A4 (16 x 544 B)
 constexpr int kF16LdsBytes = kR1Bytes + kR2Bytes + 2 * kBlobLds;
 
 __global__ __launch_bounds__(256) void lite_back_f16_kernel(const _Float16 *__restrict__ a2, LiteF16Args k, int B, float *__restrict__ probs,
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void lite_back_f16_kernel(const _Float16 *__re
             }
         }
         __syncthreads();
-        // ---- depthwise 3 (3x3, stride 2, 'same'): D3[row = clip * P3 + pixel][32] in R2, row stride 80 B
+        // ---- depthwise 3 (3x3, stride 2, 'same'): D3[row = clip * P3 + pixel][32] in R2, row stride 96 B
         for (int i = tid; i < rows * 8; i += 256) {
             const int g = i & 7, row = i >> 3, c = row / P3, p = row - c * P3, oy = p / k.W3, ox = p - oy * k.W3;
             float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -121,16 +122,16 @@ __global__ __launch_bounds__(256) void lite_back_f16_kernel(const _Float16 *__re
                 }
             }
             f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
-            *reinterpret_cast<f16x4 *>(R2 + row * 80 + 8 * g) = h;
+            *reinterpret_cast<f16x4 *>(R2 + row * 96 + 8 * g) = h;
         }
         __syncthreads();
-        // ---- pointwise 3 (32 -> 64) + bias + relu (cnn.py:113), BN, ReLU6: A3[row][64] in R1, row stride 144 B
+        // ---- pointwise 3 (32 -> 64) + bias + relu (cnn.py:113), BN, ReLU6: A3[row][64] in R1, row stride 160 B
         {
             f16x8 bf[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) bf[nt] = *reinterpret_cast<const f16x8 *>(Wl + kBlobW3 + (16 * nt + li) * kW3Row + 8 * lq);
             for (int mt = wave; mt < mtiles; mt += 4) {
-                const f16x8 af = *reinterpret_cast<const f16x8 *>(R2 + (16 * mt + li) * 80 + 16 * lq);
+                const f16x8 af = *reinterpret_cast<const f16x8 *>(R2 + (16 * mt + li) * 96 + 16 * lq);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     const f32x4 acc = mfma_f16(af, bf[nt], (f32x4){0.f, 0.f, 0.f, 0.f});
@@ -138,13 +139,13 @@ __global__ __launch_bounds__(256) void lite_back_f16_kernel(const _Float16 *__re
                     const float bias = k.pwb3[col], sc = k.sc3[col], sh = k.sh3[col];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        *reinterpret_cast<_Float16 *>(R1 + (16 * mt + 4 * lq + r) * 144 + 2 * col) =
+                        *reinterpret_cast<_Float16 *>(R1 + (16 * mt + 4 * lq + r) * 160 + 2 * col) =
                             (_Float16)relu6f(fmaf(fmaxf(acc[r] + bias, 0.f), sc, sh));
                 }
             }
         }
         __syncthreads();
-        // ---- depthwise 4 (3x3, stride 1, 'same') over the (H3 x W3) map: D4[row][64] in R2, row stride 144 B
+        // ---- depthwise 4 (3x3, stride 1, 'same') over the (H3 x W3) map: D4[row][64] in R2, row stride 160 B
         for (int i = tid; i < rows * 16; i += 256) {
             const int g = i & 15, row = i >> 4, c = row / P3, p = row - c * P3, oy = p / k.W3, ox = p - oy * k.W3;
             float o[4] = {0.f, 0.f, 0.f, 0.f};
@@ -152,19 +153,19 @@ __global__ __launch_bounds__(256) void lite_back_f16_kernel(const _Float16 *__re
             for (int t = 0; t < 9; ++t) {
                 const int y = oy + t / 3 - 1, x = ox + t % 3 - 1;
                 if (y >= 0 && y < k.H3 && x >= 0 && x < k.W3) {
-                    const f16x4 v = *reinterpret_cast<const f16x4 *>(R1 + (c * P3 + y * k.W3 + x) * 144 + 8 * g);
+                    const f16x4 v = *reinterpret_cast<const f16x4 *>(R1 + (c * P3 + y * k.W3 + x) * 160 + 8 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = fmaf((float)v[e], w4[t][e], o[e]);
                 }
             }
             f16x4 h = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
-            *reinterpret_cast<f16x4 *>(R2 + row * 144 + 8 * g) = h;
+            *reinterpret_cast<f16x4 *>(R2 + row * 160 + 8 * g) = h;
         }
         __syncthreads();
-        // ---- pointwise 4 (64 -> 128) + bias + relu (cnn.py:122), BN, ReLU6: Z4[row][128] in R1, row stride 272 B
+        // ---- pointwise 4 (64 -> 128) + bias + relu (cnn.py:122), BN, ReLU6: Z4[row][128] in R1, row stride 288 B
         for (int mt = wave; mt < mtiles; mt += 4) {
-            const f16x8 a0 = *reinterpret_cast<const f16x8 *>(R2 + (16 * mt + li) * 144 + 16 * lq);
-            const f16x8 a1 = *reinterpret_cast<const f16x8 *>(R2 + (16 * mt + li) * 144 + 64 + 16 * lq);
+            const f16x8 a0 = *reinterpret_cast<const f16x8 *>(R2 + (16 * mt + li) * 160 + 16 * lq);
+            const f16x8 a1 = *reinterpret_cast<const f16x8 *>(R2 + (16 * mt + li) * 160 + 64 + 16 * lq);
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
                 const f16x8 b0f = *reinterpret_cast<const f16x8 *>(Wl + kBlobW4 + (16 * nt + li) * kW4Row + 8 * lq);
@@ -175,34 +176,34 @@ __global__ __launch_bounds__(256) void lite_back_f16_kernel(const _Float16 *__re
                 const float bias = k.pwb4[col], sc = k.sc4[col], sh = k.sh4[col];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    *reinterpret_cast<_Float16 *>(R1 + (16 * mt + 4 * lq + r) * 272 + 2 * col) =
+                    *reinterpret_cast<_Float16 *>(R1 + (16 * mt + 4 * lq + r) * 288 + 2 * col) =
                         (_Float16)relu6f(fmaf(fmaxf(acc[r] + bias, 0.f), sc, sh));
             }
         }
         __syncthreads();
-        // ---- 2x2 max-pool + flatten (h, w, c): A4[clip][flat] in R2, row stride 528 B
+        // ---- 2x2 max-pool + flatten (h, w, c): A4[clip][flat] in R2, row stride 544 B
         for (int i = tid; i < kF16Clips * n4 * 128; i += 256) {
             const int ch = i & 127, q = i >> 7, c = q / n4, w = q - c * n4, ph = w / k.W4, pw = w - ph * k.W4;
-            const unsigned char *z = R1 + (c * P3 + 2 * ph * k.W3 + 2 * pw) * 272 + 2 * ch;
-            const float m = fmaxf(fmaxf((float)*reinterpret_cast<const _Float16 *>(z), (float)*reinterpret_cast<const _Float16 *>(z + 272)),
-                                  fmaxf((float)*reinterpret_cast<const _Float16 *>(z + k.W3 * 272),
-                                        (float)*reinterpret_cast<const _Float16 *>(z + (k.W3 + 1) * 272)));
-            *reinterpret_cast<_Float16 *>(R2 + c * 528 + 2 * (w * 128 + ch)) = (_Float16)m;
+            const unsigned char *z = R1 + (c * P3 + 2 * ph * k.W3 + 2 * pw) * 288 + 2 * ch;
+            const float m = fmaxf(fmaxf((float)*reinterpret_cast<const _Float16 *>(z), (float)*reinterpret_cast<const _Float16 *>(z + 288)),
+                                  fmaxf((float)*reinterpret_cast<const _Float16 *>(z + k.W3 * 288),
+                                        (float)*reinterpret_cast<const _Float16 *>(z + (k.W3 + 1) * 288)));
+            *reinterpret_cast<_Float16 *>(R2 + c * 544 + 2 * (w * 128 + ch)) = (_Float16)m;
         }
         __syncthreads();
-        // ---- Dense(128) + bias + ReLU6 (cnn.py:129): D1[clip][128] in R1, row stride 272 B; the kernel streams from L2
+        // ---- Dense(128) + bias + ReLU6 (cnn.py:129): D1[clip][128] in R1, row stride 288 B; the kernel streams from L2
         for (int nt = 2 * wave; nt < 2 * wave + 2; ++nt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             const _Float16 *wrow = k.blob + kBlobWd + (16 * nt + li) * kWdRow + 8 * lq;
             for (int ks = 0; ks < flat / 32; ++ks) {
                 const f16x8 bfr = *reinterpret_cast<const f16x8 *>(wrow + 32 * ks);
-                const f16x8 afr = *reinterpret_cast<const f16x8 *>(R2 + li * 528 + 64 * ks + 16 * lq);
+                const f16x8 afr = *reinterpret_cast<const f16x8 *>(R2 + li * 544 + 64 * ks + 16 * lq);
                 acc = mfma_f16(afr, bfr, acc);
             }
             const int col = 16 * nt + li;
             const float bias = k.db[col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) *reinterpret_cast<_Float16 *>(R1 + (4 * lq + r) * 272 + 2 * col) = (_Float16)relu6f(acc[r] + bias);
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<_Float16 *>(R1 + (4 * lq + r) * 288 + 2 * col) = (_Float16)relu6f(acc[r] + bias);
         }
         __syncthreads();
         // ---- head: logits[clip][C] (fp32) behind D1 in R1
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void lite_back_f16_kernel(const _Float16 *__re
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const f16x8 afr = *reinterpret_cast<const f16x8 *>(R1 + li * 272 + 64 * ks + 16 * lq);
+                const f16x8 afr = *reinterpret_cast<const f16x8 *>(R1 + li * 288 + 64 * ks + 16 * lq);
                 const f16x8 bfr = *reinterpret_cast<const f16x8 *>(Wl + kBlobW2 + (16 * wave + li) * kW2Row + 32 * ks + 8 * lq);
                 acc = mfma_f16(afr, bfr, acc);
             }

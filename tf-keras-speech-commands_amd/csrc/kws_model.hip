@@ -335,7 +335,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             // conv2: clip-resident kernel, batch statistics fused into the epilogue when training
             const unsigned nblk = (unsigned)std::min(B, kMaxStatBlocks);
             const size_t sm = std::max(sizeof(float) * (size_t)(Hs[1] + 2) * (Ws[1] + 2) * 20, sizeof(double) * 4 * 2 * 32);
-            const size_t smb = std::max((size_t)6 * 16 * (Hs[1] + 2) * (Ws[1] + 2), sizeof(double) * 4 * 2 * 16);
+            const size_t smb = std::max((size_t)6 * 16 * (((Hs[1] + 2) * (Ws[1] + 2) + 15) & ~15), sizeof(double) * 4 * 2 * 16);
             if (training && bf16) {
                 KWS_LAUNCH("conv_fwd_clip_bf16<16,32>", (conv_fwd_clip_bf16_kernel<true>), dim3(nblk), dim3(256), smb, s, in, kern, w.z[1], B, Hs[1],
                            Ws[1], w.partial, kStatStride);
@@ -520,7 +520,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (compact_g) { bn.gw = w.da[1]; bn.arg = reinterpret_cast<const unsigned char *>(w.da[2]); }
             if (g_matrix_precision == 1) {
                 // split-precision form: 2 blocks per CU by registers (the weight fragments of all nine taps stay in them)
-                const size_t smdb = (size_t)12 * 16 * (H1 + 2) * (W1 + 2);
+                const size_t smdb = (size_t)12 * 16 * (((H1 + 2) * (W1 + 2) + 15) & ~15);
                 if (compact_g)
                     KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s,
                                w.gz[1], kern, w.da[0], B, H1, W1, bn);

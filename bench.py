@@ -74,8 +74,11 @@ def kernel_models(B, C):
     m["conv_dgrad<32,16>"] = ("mfma", 2.0 * B * 150 * 9 * 16 * 32)
     m["conv_dgrad<64,32>"] = ("mfma", 2.0 * B * 12 * 9 * 32 * 64)         # one launch over the four stride-2 parity classes
     # conv2 runs in the clip-resident LDS kernels (kws_conv.h: conv_fwd_clip / conv_dgrad_clip / conv_wgrad_clip)
-    for k in ("conv_fwd_clip<16,32>", "conv_wgrad_clip<16,32>", "conv_dgrad_clip<32,16>"):
+    # (fp32 MFMA) and their three-way bf16 split forms (default precision)
+    for k in ("conv_fwd_clip<16,32>", "conv_wgrad_clip<16,32>", "conv_dgrad_clip<32,16>", "conv_fwd_clip_bf16<16,32>",
+              "conv_wgrad_clip_bf16<16,32>", "conv_dgrad_clip_bf16<32,16>"):
         m[k] = ("mfma", 2.0 * B * 150 * 9 * 16 * 32)
+    m["conv_wgrad_bf16<64,128>"] = ("mfma", 2.0 * B * 12 * 9 * 64 * 128)
     m["conv_dgrad<128,64>"] = ("mfma", 2.0 * B * 12 * 9 * 64 * 128)
     m["conv_dgrad<128,128>"] = ("mfma", 2.0 * B * 256 * 128)
     for l in range(1, 4):
@@ -255,8 +258,9 @@ def main():
                "config": {"workload": "configs[1]: simple_cnn train step = featurize(f32 1 s @16 kHz) + fwd + bwd + Adam, "
                                       "36 logits (background + 35 words), batch %d per GPU" % B,
                           "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
-                          "matrix_precision": "conv3/conv4/dense as three-way bf16 splits on the bf16 matrix cores with fp32 "
-                                              "accumulation (fp32-level error, kws_set_matrix_precision); everything else fp32",
+                          "matrix_precision": "conv2/conv3/conv4/dense products as three-way bf16 splits on the bf16 matrix cores "
+                                              "with fp32 accumulation (fp32-level error, kws_set_matrix_precision); conv1, conv3 "
+                                              "data/weight gradients, dense weight gradient and everything else fp32",
                           "input_pipeline": "features of batch k+1 computed on a side stream during step k (all K inside the timed region)",
                           "train_step_hbm_roofline_frac": round(value / world * 229.8e3 / (HBM_PEAK_GBS * 1e9), 4)},
                "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,

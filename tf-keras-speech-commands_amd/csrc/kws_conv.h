@@ -400,7 +400,10 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char *p)
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(p));
 }
 
-template <int CIN, int COUT>
+// TPB = taps per block: 1, or KW (= 3: one kernel row).  With three taps per block the dz chunk is staged and split once
+// for three products and the wave does 3 x MT x NW MFMA groups per chunk, which moves the kernel from issue-bound on the
+// split arithmetic (one tap: ~250 vector instructions beside 48 MFMAs per wave and chunk) to matrix-bound.
+template <int CIN, int COUT, int TPB>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dzp,
                                                                   float *__restrict__ dw, const float *__restrict__ zero_page,
                                                                   ConvGeom g, int chunks_per_block, int nranges)
@@ -410,27 +413,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
     constexpr int MT = CIN / 16, NT = COUT / 16, NW = NT / 4;     // row tiles, column tiles, column tiles per wave
     constexpr int XU = KC * CIN / 4, DU = KC * COUT / 4;          // float4 units of a chunk
     constexpr int NXU = XU / 256, NDU = DU / 256;
+    constexpr int XT = 3 * KC * XS;                               // bytes of one tap's x planes
     static_assert(COUT % 64 == 0 && CIN % 32 == 0, "four waves split COUT in 16-column tiles; every thread stages whole units");
-    static_assert(3 * KC * (XS + DS) >= CIN * COUT * 4, "the staging space also holds the block's tile at the end");
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
-    unsigned char *Xs = wsm;                                      // [3][KC][XS]
-    unsigned char *Ds = wsm + 3 * KC * XS;                        // [3][KC][DS]
+    unsigned char *Xs = wsm;                                      // [TPB][3][KC][XS]
+    unsigned char *Ds = wsm + TPB * XT;                           // [3][KC][DS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lq = lane >> 4;
     const int HW = g.Ho * g.Wo;
     const long M = (long)g.B * HW;
-    const int ntaps = g.KH * g.KW;
-    // block id -> (tap, range): XCD = id % 8 holds every tap of its ranges
-    const int bid = blockIdx.x, tap = (bid >> 3) % ntaps, range = (bid / (8 * ntaps)) * 8 + (bid & 7);
-    const int kh = tap / g.KW, kw = tap % g.KW;
+    const int ngroups = g.KH * g.KW / TPB;                        // tap groups (TPB == KW: kernel rows)
+    // block id -> (tap group, range): XCD = id % 8 holds every tap of its ranges
+    const int bid = blockIdx.x, tap0 = ((bid >> 3) % ngroups) * TPB, range = (bid / (8 * ngroups)) * 8 + (bid & 7);
     const long nchunk_all = (M + KC - 1) / KC, chunk0 = (long)range * chunks_per_block;
     const int nchunks = (range >= nranges || chunk0 >= nchunk_all) ? 0
                         : (int)(chunk0 + chunks_per_block <= nchunk_all ? chunks_per_block : nchunk_all - chunk0);
 
-    f32x4 acc[MT][NW];
+    f32x4 acc[TPB][MT][NW];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int t = 0; t < TPB; ++t)
 #pragma unroll
-        for (int nw = 0; nw < NW; ++nw) acc[mt][nw] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nw = 0; nw < NW; ++nw) acc[t][mt][nw] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // staging units: unit u -> float4 e = u % (C/4) of pixel p = u / (C/4): coalesced global reads, contiguous LDS rows.
     // The unit's clip and pixel-in-clip advance by 32 pixels per chunk without divisions; rows past M and taps that fall
@@ -442,17 +446,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
         const long m = chunk0 * KC + (tid + 256 * j) / (CIN / 4);
         xb[j] = (int)(m / HW); xpix[j] = (int)(m - (long)xb[j] * HW);
     }
-    struct Staged { f32x4 x[NXU], d[NDU]; };
-    auto load_chunk = [&](int ch, Staged &st) {
+    f32x4 sx[TPB][NXU], sd[NDU];
+    auto load_chunk = [&](int ch) {
         const long m0 = (chunk0 + ch) * KC;
 #pragma unroll
         for (int j = 0; j < NXU; ++j) {
             const int e = (tid + 256 * j) % (CIN / 4);
             const int oy = (int)(((float)xpix[j] + 0.5f) * rWo), ox = xpix[j] - oy * g.Wo;
-            const int sy = oy * g.stride + kh - g.pt, sx = ox * g.stride + kw - g.pl;
-            const bool ok = xb[j] < g.B && sy >= 0 && sy < g.H && sx >= 0 && sx < g.W;
-            const float *p = ok ? x + (((long)xb[j] * g.H + sy) * g.W + sx) * CIN + 4 * e : zero_page;
-            st.x[j] = *reinterpret_cast<const f32x4 *>(p);
+#pragma unroll
+            for (int t = 0; t < TPB; ++t) {
+                const int tap = tap0 + t, kh = tap / g.KW, kw = tap - kh * g.KW;
+                const int sy = oy * g.stride + kh - g.pt, sxx = ox * g.stride + kw - g.pl;
+                const bool ok = xb[j] < g.B && sy >= 0 && sy < g.H && sxx >= 0 && sxx < g.W;
+                const float *p = ok ? x + (((long)xb[j] * g.H + sy) * g.W + sxx) * CIN + 4 * e : zero_page;
+                sx[t][j] = *reinterpret_cast<const f32x4 *>(p);
+            }
             xpix[j] += KC;
             while (xpix[j] >= HW) { xpix[j] -= HW; ++xb[j]; }
         }
@@ -461,27 +469,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
             const int u = tid + 256 * j;
             const long m = m0 + u / (COUT / 4);
             const float *p = m < M ? dzp + m * COUT + 4 * (u % (COUT / 4)) : zero_page;
-            st.d[j] = *reinterpret_cast<const f32x4 *>(p);
+            sd[j] = *reinterpret_cast<const f32x4 *>(p);
         }
     };
-    auto store_chunk = [&](const Staged &st) {
+    auto store_planes = [&](unsigned char *base, int plane_bytes, int o, f32x4 v) {
+        bf16x4 h, m, l;
+        split_bf16(v, h, m, l);
+        *reinterpret_cast<bf16x4 *>(base + o) = h;
+        *reinterpret_cast<bf16x4 *>(base + plane_bytes + o) = m;
+        *reinterpret_cast<bf16x4 *>(base + 2 * plane_bytes + o) = l;
+    };
+    auto store_chunk = [&]() {
 #pragma unroll
         for (int j = 0; j < NXU; ++j) {
             const int u = tid + 256 * j, o = (u / (CIN / 4)) * XS + 8 * (u % (CIN / 4));
-            bf16x4 h, m, l;
-            split_bf16(st.x[j], h, m, l);
-            *reinterpret_cast<bf16x4 *>(Xs + o) = h;
-            *reinterpret_cast<bf16x4 *>(Xs + KC * XS + o) = m;
-            *reinterpret_cast<bf16x4 *>(Xs + 2 * KC * XS + o) = l;
+#pragma unroll
+            for (int t = 0; t < TPB; ++t) store_planes(Xs + t * XT, KC * XS, o, sx[t][j]);
         }
 #pragma unroll
         for (int j = 0; j < NDU; ++j) {
             const int u = tid + 256 * j, o = (u / (COUT / 4)) * DS + 8 * (u % (COUT / 4));
-            bf16x4 h, m, l;
-            split_bf16(st.d[j], h, m, l);
-            *reinterpret_cast<bf16x4 *>(Ds + o) = h;
-            *reinterpret_cast<bf16x4 *>(Ds + KC * DS + o) = m;
-            *reinterpret_cast<bf16x4 *>(Ds + 2 * KC * DS + o) = l;
+            store_planes(Ds, KC * DS, o, sd[j]);
         }
     };
     // transposed fragment: lane 4q+pp of a group supplies row q, channels 4pp..4pp+3 of the 16-channel tile
@@ -495,53 +503,44 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
         return u.v;
     };
 
-    auto mma_chunk = [&]() {
+    // one chunk of global loads in flight (a second set changed nothing when it was tried with one tap per block)
+    if (nchunks > 0) load_chunk(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
         bf16x8 b[NW][3];
 #pragma unroll
         for (int nw = 0; nw < NW; ++nw)
 #pragma unroll
             for (int p = 0; p < 3; ++p) b[nw][p] = frag(dfrag, DS, p, nw);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            bf16x8 a[3];
+        for (int t = 0; t < TPB; ++t)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) a[p] = frag(xfrag, XS, p, mt);
+            for (int mt = 0; mt < MT; ++mt) {
+                bf16x8 a[3];
 #pragma unroll
-            for (int nw = 0; nw < NW; ++nw) acc[mt][nw] = mfma_bf16x6(a, b[nw], acc[mt][nw]);
-        }
-    };
-    // two chunks of global loads in flight (two register sets, loop unrolled by two): the nine tap blocks of a range
-    // fetch the same lines, so per range only one chunk's worth of bytes is outstanding and one MFMA phase does not
-    // cover a miss
-    Staged s0, s1;
-    if (nchunks > 0) load_chunk(0, s0);
-    if (nchunks > 1) load_chunk(1, s1);
-    for (int ch = 0; ch < nchunks; ch += 2) {
-        __syncthreads();
-        store_chunk(s0);
-        __syncthreads();
-        if (ch + 2 < nchunks) load_chunk(ch + 2, s0);
-        mma_chunk();
-        if (ch + 1 < nchunks) {
-            __syncthreads();
-            store_chunk(s1);
-            __syncthreads();
-            if (ch + 3 < nchunks) load_chunk(ch + 3, s1);
-            mma_chunk();
-        }
+                for (int p = 0; p < 3; ++p) a[p] = frag(xfrag + t * XT, XS, p, mt);
+#pragma unroll
+                for (int nw = 0; nw < NW; ++nw) acc[t][mt][nw] = mfma_bf16x6(a, b[nw], acc[t][mt][nw]);
+            }
     }
-    // gather the block's (CIN x COUT) tile in LDS (reusing the staging space) and add it with contiguous atomics
-    __syncthreads();
+    // gather each tap's (CIN x COUT) tile in LDS (reusing the staging space) and add it with contiguous atomics
     float *red = reinterpret_cast<float *>(wsm);                   // [CIN][COUT]
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int t = 0; t < TPB; ++t) {
+        __syncthreads();
 #pragma unroll
-        for (int nw = 0; nw < NW; ++nw)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[(16 * mt + 4 * lq + r) * COUT + 16 * (wave * NW + nw) + li] = acc[mt][nw][r];
-    __syncthreads();
-    if (nchunks > 0)
-        for (int i = tid; i < CIN * COUT; i += 256) atomicAdd(dw + (long)tap * CIN * COUT + i, red[i]);
+            for (int nw = 0; nw < NW; ++nw)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(16 * mt + 4 * lq + r) * COUT + 16 * (wave * NW + nw) + li] = acc[t][mt][nw][r];
+        __syncthreads();
+        if (nchunks > 0)
+            for (int i = tid; i < CIN * COUT; i += 256) atomicAdd(dw + (long)(tap0 + t) * CIN * COUT + i, red[i]);
+    }
 }
 
 // N consecutive floats with the widest aligned load (N = 1, 2, 4, 8); p must be N*4-byte aligned (16 for N = 8)

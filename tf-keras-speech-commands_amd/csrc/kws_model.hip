@@ -154,25 +154,27 @@ void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g,
                s, x, dz, dw, zero_page(), g, spw);
 }
 
-// dW += wgrad(x, dz) in the split-precision form (conv_wgrad_bf16_kernel): grid = ntaps * (pixel ranges), one resident round
-// of 2 blocks per CU, the taps of a range on one XCD.
-template <int CIN, int COUT>
+// dW += wgrad(x, dz) in the split-precision form (conv_wgrad_bf16_kernel): grid = (tap groups) * (pixel ranges), one resident
+// round, the taps of a range on one XCD.  TPB = taps per block: 3 (one kernel row, dz split once for three products) pays
+// for conv3 (0.047 -> 0.042 ms); for conv4 its 238 registers and 74 KB of LDS cost more than they save (0.111 -> 0.122 ms).
+template <int CIN, int COUT, int TPB>
 void launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s)
 {
-    constexpr size_t stage = (size_t)3 * 32 * 4 * (tr_row_words(CIN) + tr_row_words(COUT)), tile = (size_t)CIN * COUT * sizeof(float);
+    if (TPB != 1 && g.KW != TPB) { fail(KWS_ERR_UNSUPPORTED, "split-precision weight gradient expects a kernel %d taps wide", TPB); return; }
+    constexpr size_t stage = (size_t)3 * 32 * 4 * (TPB * tr_row_words(CIN) + tr_row_words(COUT)), tile = (size_t)CIN * COUT * sizeof(float);
     constexpr size_t smem = stage > tile ? stage : tile;
     static const int occ = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        return resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT>, 256, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        return resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB>, 256, smem);
     }();
     const long M = (long)g.B * g.Ho * g.Wo, nchunk = (M + 31) / 32;
-    const int ntaps = g.KH * g.KW;
+    const int ngroups = g.KH * g.KW / TPB;
     // ranges: a multiple of 8 (one per XCD), at most one resident round, at least 4 chunks per block
-    long nranges = std::max<long>(8, ((long)cu_count() * occ / ntaps) / 8 * 8);
+    long nranges = std::max<long>(8, ((long)cu_count() * occ / ngroups) / 8 * 8);
     nranges = std::min<long>(nranges, std::max<long>(8, (nchunk / 4 + 7) / 8 * 8));
     const int cpb = (int)((nchunk + nranges - 1) / nranges);
     static const std::string name = "conv_wgrad_bf16<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
-    KWS_LAUNCH(name.c_str(), (conv_wgrad_bf16_kernel<CIN, COUT>), dim3((unsigned)(nranges * ntaps)), dim3(256), smem, s, x, dz, dw,
+    KWS_LAUNCH(name.c_str(), (conv_wgrad_bf16_kernel<CIN, COUT, TPB>), dim3((unsigned)(nranges * ngroups)), dim3(256), smem, s, x, dz, dw,
                zero_page(), g, cpb, (int)nranges);
 }
 
@@ -491,7 +493,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
-            if (g_matrix_precision == 1) launch_wgrad_bf16<64, 128>(in, w.gz[3], dk, g, s2);
+            if (g_matrix_precision == 1) launch_wgrad_bf16<64, 128, 1>(in, w.gz[3], dk, g, s2);
             else launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);
             if (bucket_event) {
                 // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here: it
@@ -504,7 +506,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             else launch_dgrad<128, 64, 1>(w.gz[3], kern, w.da[2], g, s);
         } else if (l == 2) {
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
-            launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2);
+            if (g_matrix_precision == 1) launch_wgrad_bf16<32, 64, 3>(in, w.gz[2], dk, g, s2);
+            else launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2);
             launch_dgrad<64, 32, 2>(w.gz[2], kern, w.da[1], g, s);
         } else {
             // conv2 (16 -> 32, 3x3, stride 1): clip-resident kernels, the clip's tiles are staged in LDS once

@@ -291,14 +291,30 @@ struct L1Mma {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    // z of tile t: lane (li, lq) gets the four elements of window 4t + lq for channel li
-    __device__ __forceinline__ f32x4 z(int t) const
+    // The tiles of a clip are visited in order, so the pool-window coordinates of a lane advance by four windows per tile
+    // without a division (an integer division by the runtime Wp per tile was a fifth of these kernels' instructions):
+    // (aph, apw) is the A-side window 4 t + (li >> 2) of the z product, (dph, dpw) the D-side window 4 t + lq whose four
+    // elements the lane receives.
+    int aph, apw, dph, dpw;
+    __device__ __forceinline__ void first_tile()
     {
-        const int lane = threadIdx.x & 63, li = lane & 15;
-        int win = 4 * t + (li >> 2);
-        win = win < nwin ? win : 0;                // windows past the clip are clamped (their results are masked by the caller)
-        const int ph = win / Wp, pw = win - ph * Wp, e = li & 3;
-        const float *base = xs + (2 * ph + (e >> 1)) * WP + 2 * pw + (e & 1);
+        const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+        aph = (li >> 2) / Wp; apw = (li >> 2) - aph * Wp;
+        dph = lq / Wp; dpw = lq - dph * Wp;
+    }
+    __device__ __forceinline__ void next_tile()
+    {
+        apw += 4; while (apw >= Wp) { apw -= Wp; ++aph; }
+        dpw += 4; while (dpw >= Wp) { dpw -= Wp; ++dph; }
+    }
+    // LDS offset of element (0, 0) of the lane's D-side window (window 0 when the window lies past the clip)
+    __device__ __forceinline__ int d_window_offset(bool ok) const { return ok ? (2 * dph) * WP + 2 * dpw : 0; }
+    // z of the current tile: lane (li, lq) gets the four elements of window 4t + lq for channel li
+    __device__ __forceinline__ f32x4 z() const
+    {
+        const int lane = threadIdx.x & 63, li = lane & 15, e = li & 3;
+        const bool in = aph < (nwin / Wp);         // windows past the clip are clamped to window 0 (their results are masked by the caller)
+        const float *base = xs + (in ? (2 * aph) * WP + 2 * apw : 0) + (e >> 1) * WP + (e & 1);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc = mfma16(base[aoff[j]], wb[j], acc);
@@ -362,8 +378,9 @@ __global__ __launch_bounds__(256) void l1m_stats_kernel(const float *__restrict_
         t.store();
         if (i + 1 < count) t.fetch(feat, first + i + 1);
         float fs = 0.f, fss = 0.f;
-        for (int tile = 0; tile < t.ntile; ++tile) {
-            const f32x4 z = t.z(tile);
+        t.first_tile();
+        for (int tile = 0; tile < t.ntile; ++tile, t.next_tile()) {
+            const f32x4 z = t.z();
             if (4 * tile + lq < t.nwin) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { fs += z[r]; fss = fmaf(z[r], z[r], fss); }
@@ -392,8 +409,9 @@ __global__ __launch_bounds__(256) void l1m_act_pool_kernel(const float *__restri
         t.store();
         if (i + 1 < count) t.fetch(feat, first + i + 1);
         float *out = a1 + (first + i) * t.nwin * 16 + li;
-        for (int tile = 0; tile < t.ntile; ++tile) {
-            const f32x4 z = t.z(tile);
+        t.first_tile();
+        for (int tile = 0; tile < t.ntile; ++tile, t.next_tile()) {
+            const f32x4 z = t.z();
             const float y0 = fmaf(z[0], sc, sh), y1 = fmaf(z[1], sc, sh), y2 = fmaf(z[2], sc, sh), y3 = fmaf(z[3], sc, sh);
             const int win = 4 * tile + lq;
             if (win < t.nwin) out[win * 16] = relu6f(fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
@@ -428,6 +446,7 @@ __global__ __launch_bounds__(256, 4) void l1m_bwd_reduce_kernel(const float *__r
         t.store();
         if (i + 1 < count) t.fetch(feat, first + i + 1);
         float fs = 0.f, fsx = 0.f;
+        t.first_tile();
         for (int t0 = 0; t0 < t.ntile; t0 += kL1Group) {
 #pragma unroll
             for (int j = 0; j < kL1Group; ++j) dcur[j] = dnxt[j];
@@ -436,7 +455,8 @@ __global__ __launch_bounds__(256, 4) void l1m_bwd_reduce_kernel(const float *__r
             for (int j = 0; j < kL1Group; ++j) {
                 const int tile = t0 + j;
                 if (tile < t.ntile) {
-                    const f32x4 z = t.z(tile);
+                    const f32x4 z = t.z();
+                    t.next_tile();
                     int arg;
                     float g;
                     l1m_route(z, sc, sh, dcur[j], arg, g);
@@ -480,6 +500,7 @@ __global__ __launch_bounds__(256, 4) void l1m_bwd_wgrad_kernel(const float *__re
         fetch_da(0, dnxt);
         t.store();
         if (i + 1 < count) t.fetch(feat, first + i + 1);
+        t.first_tile();
         for (int t0 = 0; t0 < t.ntile; t0 += kL1Group) {
 #pragma unroll
             for (int j = 0; j < kL1Group; ++j) dcur[j] = dnxt[j];
@@ -490,12 +511,12 @@ __global__ __launch_bounds__(256, 4) void l1m_bwd_wgrad_kernel(const float *__re
                 if (tile < t.ntile) {
                     const int win = 4 * tile + lq;
                     const bool ok = win < t.nwin;
-                    const f32x4 z = t.z(tile);
+                    const f32x4 z = t.z();
                     int arg;
                     float g;
                     l1m_route(z, sc, sh, dcur[j], arg, g);
-                    const int wq = ok ? win : 0, ph = wq / t.Wp, pw = wq - ph * t.Wp;
-                    const float *xb = t.xs + (2 * ph) * t.WP + 2 * pw + boff;
+                    const float *xb = t.xs + t.d_window_offset(ok) + boff;
+                    t.next_tile();
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float dz = k1 * ((r == arg ? g : 0.f) - k2 - (z[r] - mean) * inv * k3);

@@ -208,10 +208,13 @@ struct Bf16Planes { const __bf16 *p[3]; };
 // fragments and the staged chunk in VGPRs (at the default occupancy target the compiler spilled into the K loop)
 // STATS: the epilogue also writes the BatchNorm partial sums of the block's outputs (sum and sum of squares per column, in
 // double) to partial[(which*CO + n)*partial_stride + blockIdx.x], which replaces a separate pass over the conv output.
-template <int CR, int CO, int MODE, int EPI, int RT, bool STATS = false>
+// APRE: the A operand arrives already split (planes `ap` in the layout of `src`, which is then unused): staging copies 16-byte
+// pieces (one unit = 8 channels of a row) instead of splitting -- nine taps re-stage every row, so the split was done nine times.
+template <int CR, int CO, int MODE, int EPI, int RT, bool STATS = false, bool APRE = false>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restrict__ src, Bf16Planes wp, const float *__restrict__ bias,
                                                          float *__restrict__ dst, ConvGeom g, double *__restrict__ partial = nullptr,
-                                                         int partial_stride = 0, const float *__restrict__ shift = nullptr)
+                                                         int partial_stride = 0, const float *__restrict__ shift = nullptr,
+                                                         Bf16Planes ap = Bf16Planes{{nullptr, nullptr, nullptr}})
 {
     // chunk depth and LDS row stride in bf16 units.  96-byte rows: ds_read_b128 serves the lane groups {0-3,12-15,20-27}, ... (not
     // 16 consecutive lanes), and fragment reads at (row li, 16-byte piece lq) are conflict-free for strides of 16 B x (2 mod 4);
@@ -220,7 +223,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
     constexpr int BM = 32 * RT;                // rows per block: RT row tiles per wave, 2 waves along M
     constexpr int NT = CO / 16, CT = NT / 2;   // column tiles per wave (2 waves along N)
     constexpr int CPT = CR / KC;
-    constexpr int NAU = BM * 8 / 256;          // float4 A units per thread (3)
+    constexpr int UPR = APRE ? 4 : 8;          // A units per row: 8 channels (16 B of a plane) or 4 channels (one float4)
+    constexpr int NAU = BM * UPR / 256;        // A units per thread
+    static_assert(BM * UPR % 256 == 0, "every thread stages the same number of A units");
     constexpr int NBU = CO * 4 / 256;          // 16-byte B units per thread and plane
     static_assert(CO * 4 % 256 == 0, "every thread stages the same number of B units");
     static_assert(CR % KC == 0 && CO % 32 == 0, "reduced channels must be a multiple of 32, produced ones of 32");
@@ -235,11 +240,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
     const long m0 = (long)blockIdx.x * BM;
     const int ntaps = g.KH * g.KW, nchunks = ntaps * CPT;
 
-    int a_b[NAU], a_y[NAU], a_x[NAU];         // per-thread A-staging coordinates: row = u / 8, float4 c4 = u % 8
+    int a_b[NAU], a_y[NAU], a_x[NAU];         // per-thread A-staging coordinates: row = u / UPR, piece = u % UPR
 #pragma unroll
     for (int j = 0; j < NAU; ++j) {
         const int u = tid + 256 * j;
-        const long m = m0 + u / 8;
+        const long m = m0 + u / UPR;
         if (m < M) {
             const int pix = (int)(m % ((long)RH * RW));
             a_b[j] = (int)(m / ((long)RH * RW));
@@ -251,21 +256,24 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
     }
 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector type: HIP's uint4 struct kept these arrays in scratch
-    struct Staged { f32x4 a[NAU]; u32x4 b[3][NBU]; };
+    struct Staged { f32x4 a[APRE ? 1 : NAU]; u32x4 ap[APRE ? 3 : 1][NAU]; u32x4 b[3][NBU]; };
     auto load_chunk = [&](int chunk, Staged &st) {
         const int tap = chunk / CPT, c0 = (chunk % CPT) * KC;
         const int kh = tap / g.KW, kw = tap % g.KW;
 #pragma unroll
         for (int j = 0; j < NAU; ++j) {
             const int u = tid + 256 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_b[j] >= 0) {
-                const int sy = MODE == MODE_FWD ? a_y[j] * g.stride + kh - g.pt : a_y[j] + g.pt - kh;
-                const int sx = MODE == MODE_FWD ? a_x[j] * g.stride + kw - g.pl : a_x[j] + g.pl - kw;
-                if (sy >= 0 && sy < SH && sx >= 0 && sx < SW)
-                    v = *reinterpret_cast<const f32x4 *>(src + (((long)a_b[j] * SH + sy) * SW + sx) * CR + c0 + (u % 8) * 4);
+            const int sy = MODE == MODE_FWD ? a_y[j] * g.stride + kh - g.pt : a_y[j] + g.pt - kh;
+            const int sx = MODE == MODE_FWD ? a_x[j] * g.stride + kw - g.pl : a_x[j] + g.pl - kw;
+            const bool ok = a_b[j] >= 0 && sy >= 0 && sy < SH && sx >= 0 && sx < SW;
+            const long e = (((long)(ok ? a_b[j] : 0) * SH + (ok ? sy : 0)) * SW + (ok ? sx : 0)) * CR + c0;
+            if (APRE) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    st.ap[p][j] = ok ? *reinterpret_cast<const u32x4 *>(ap.p[p] + e + (u % UPR) * 8) : (u32x4){0u, 0u, 0u, 0u};
+            } else {
+                st.a[j] = ok ? *reinterpret_cast<const f32x4 *>(src + e + (u % UPR) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            st.a[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < NBU; ++j) {
@@ -279,12 +287,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
 #pragma unroll
         for (int j = 0; j < NAU; ++j) {
             const int u = tid + 256 * j;
-            bf16x4 h, m, l;
-            split_bf16(st.a[j], h, m, l);
-            const int o = (u / 8) * SK + 4 * (u % 8);
-            *reinterpret_cast<bf16x4 *>(&As[0][o]) = h;
-            *reinterpret_cast<bf16x4 *>(&As[1][o]) = m;
-            *reinterpret_cast<bf16x4 *>(&As[2][o]) = l;
+            if (APRE) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(&As[p][(u / UPR) * SK + 8 * (u % UPR)]) = st.ap[p][j];
+            } else {
+                bf16x4 h, m, l;
+                split_bf16(st.a[j], h, m, l);
+                const int o = (u / UPR) * SK + 4 * (u % UPR);
+                *reinterpret_cast<bf16x4 *>(&As[0][o]) = h;
+                *reinterpret_cast<bf16x4 *>(&As[1][o]) = m;
+                *reinterpret_cast<bf16x4 *>(&As[2][o]) = l;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NBU; ++j) {
@@ -403,17 +416,20 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char *p)
 // TPB = taps per block: 1, or KW (= 3: one kernel row).  With three taps per block the dz chunk is staged and split once
 // for three products and the wave does 3 x MT x NW MFMA groups per chunk, which moves the kernel from issue-bound on the
 // split arithmetic (one tap: ~250 vector instructions beside 48 MFMAs per wave and chunk) to matrix-bound.
-template <int CIN, int COUT, int TPB>
+// DPRE: dz arrives already split (planes `dpl`, NHWC like dzp, which is then unused): its staging is a 16-byte copy per plane.
+template <int CIN, int COUT, int TPB, bool DPRE = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dzp,
                                                                   float *__restrict__ dw, const float *__restrict__ zero_page,
-                                                                  ConvGeom g, int chunks_per_block, int nranges)
+                                                                  ConvGeom g, int chunks_per_block, int nranges,
+                                                                  Bf16Planes dpl = Bf16Planes{{nullptr, nullptr, nullptr}})
 {
     constexpr int KC = 32;                                        // pixels per chunk
     constexpr int XS = 4 * tr_row_words(CIN), DS = 4 * tr_row_words(COUT);   // row strides in bytes
     constexpr int MT = CIN / 16, NT = COUT / 16, NW = NT / 4;     // row tiles, column tiles, column tiles per wave
     constexpr int XU = KC * CIN / 4, DU = KC * COUT / 4;          // float4 units of a chunk
-    constexpr int NXU = XU / 256, NDU = DU / 256;
+    constexpr int NXU = XU / 256, NDU = DPRE ? DU / 2 / 256 : DU / 256;   // dz units: 8 channels of a plane or one float4
     constexpr int XT = 3 * KC * XS;                               // bytes of one tap's x planes
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     static_assert(COUT % 64 == 0 && CIN % 32 == 0, "four waves split COUT in 16-column tiles; every thread stages whole units");
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
     unsigned char *Xs = wsm;                                      // [TPB][3][KC][XS]
@@ -446,7 +462,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
         const long m = chunk0 * KC + (tid + 256 * j) / (CIN / 4);
         xb[j] = (int)(m / HW); xpix[j] = (int)(m - (long)xb[j] * HW);
     }
-    f32x4 sx[TPB][NXU], sd[NDU];
+    f32x4 sx[TPB][NXU], sd[DPRE ? 1 : NDU];
+    u32x4 sdp[DPRE ? 3 : 1][NDU];
     auto load_chunk = [&](int ch) {
         const long m0 = (chunk0 + ch) * KC;
 #pragma unroll
@@ -467,9 +484,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
 #pragma unroll
         for (int j = 0; j < NDU; ++j) {
             const int u = tid + 256 * j;
-            const long m = m0 + u / (COUT / 4);
-            const float *p = m < M ? dzp + m * COUT + 4 * (u % (COUT / 4)) : zero_page;
-            sd[j] = *reinterpret_cast<const f32x4 *>(p);
+            if (DPRE) {
+                const long m = m0 + u / (COUT / 8);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    sdp[p][j] = m < M ? *reinterpret_cast<const u32x4 *>(dpl.p[p] + m * COUT + 8 * (u % (COUT / 8))) : (u32x4){0u, 0u, 0u, 0u};
+            } else {
+                const long m = m0 + u / (COUT / 4);
+                const float *p = m < M ? dzp + m * COUT + 4 * (u % (COUT / 4)) : zero_page;
+                sd[j] = *reinterpret_cast<const f32x4 *>(p);
+            }
         }
     };
     auto store_planes = [&](unsigned char *base, int plane_bytes, int o, f32x4 v) {
@@ -488,8 +512,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
         }
 #pragma unroll
         for (int j = 0; j < NDU; ++j) {
-            const int u = tid + 256 * j, o = (u / (COUT / 4)) * DS + 8 * (u % (COUT / 4));
-            store_planes(Ds, KC * DS, o, sd[j]);
+            const int u = tid + 256 * j;
+            if (DPRE) {
+                const int o = (u / (COUT / 8)) * DS + 16 * (u % (COUT / 8));
+#pragma unroll
+                for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(Ds + p * KC * DS + o) = sdp[p][j];
+            } else {
+                store_planes(Ds, KC * DS, (u / (COUT / 4)) * DS + 8 * (u % (COUT / 4)), sd[j]);
+            }
         }
     };
     // transposed fragment: lane 4q+pp of a group supplies row q, channels 4pp..4pp+3 of the 16-channel tile

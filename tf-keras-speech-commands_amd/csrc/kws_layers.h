@@ -332,6 +332,35 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float *__restri
     gz[idx] = d;
 }
 
+// The same for a consumer that works on the three-way bf16 split (conv4's data and weight gradients): four channels per
+// thread, dz leaves as the h / m / l planes (kws_device.h: split_bf16) in the tensor's own NHWC order and the fp32 tensor
+// is not written at all -- the nine taps of the data gradient and the nine tap blocks of the weight gradient then copy
+// 16-byte pieces into LDS instead of each repeating the split.
+struct Bf16PlanesOut { __bf16 *p[3]; };
+template <bool RELU_IN>
+__global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float *__restrict__ z, const float *__restrict__ gz, BnCoef k,
+                                                                   const float *__restrict__ gamma, long total4, int C, Bf16PlanesOut out)
+{
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 >= total4) return;
+    const int c0 = (int)((i4 * 4) % C);
+    const f32x4 zv = reinterpret_cast<const f32x4 *>(z)[i4], gv = reinterpret_cast<const f32x4 *>(gz)[i4];
+    f32x4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        const float xhat = (zv[e] - k.mean[c]) * k.inv[c];
+        float v = gamma[c] * k.inv[c] * (gv[e] - k.k2[c] - xhat * k.k3[c]);
+        if (RELU_IN) v = zv[e] > 0.f ? v : 0.f;
+        d[e] = v;
+    }
+    bf16x4 h, m, l;
+    split_bf16(d, h, m, l);
+    reinterpret_cast<bf16x4 *>(out.p[0])[i4] = h;
+    reinterpret_cast<bf16x4 *>(out.p[1])[i4] = m;
+    reinterpret_cast<bf16x4 *>(out.p[2])[i4] = l;
+}
+
 // ---- head: Dense(C, softmax) 'score_predict' (classifier/model.py:37) + loss (classifier/loss.py) --------------
 // block = 16 samples.  logits -> probs, per-sample loss / correct flag, dlogits = d(mean loss)/d(logits) * grad_scale
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ d1, const float *__restrict__ w2,

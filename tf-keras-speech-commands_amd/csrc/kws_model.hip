@@ -36,6 +36,7 @@ struct CnnWs {
     float *dwo[4], *ddw[4];   // simple_cnn_lite: depthwise outputs and their gradients
     float *coef[4];     // 6*C floats per BN layer
     __bf16 *wsp[3][6];  // simple_cnn: bf16 h/m/l planes of conv3, conv4 and dense weights (original order x3, transposed x3; kws_conv.h)
+    __bf16 *dzp[3];     // simple_cnn training: h/m/l planes of dz4 (written by BN4's backward, read by conv4's data / weight gradients)
     double *partial;    // [kMaxStatBlocks][2][256]
     size_t bytes;
 };
@@ -71,6 +72,7 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
         w.dd1 = take((size_t)B * 128);
         w.da4 = take((size_t)B * d.flat);
         for (int i = 0; i < 4; ++i) w.gz[i] = take((i == 0 && !lite) ? 0 : zs[i] * B);
+        for (int p = 0; p < 3; ++p) w.dzp[p] = reinterpret_cast<__bf16 *>(take(lite ? 0 : (zs[3] * B + 1) / 2));
         for (int i = 0; i < 4; ++i) w.ddw[i] = take(lite ? dws[i] * B : 0);
         for (int i = 0; i < 3; ++i) w.da[i] = take(as[i] * B);
     }
@@ -157,15 +159,15 @@ void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g,
 // dW += wgrad(x, dz) in the split-precision form (conv_wgrad_bf16_kernel): grid = (tap groups) * (pixel ranges), one resident
 // round, the taps of a range on one XCD.  TPB = taps per block: 3 (one kernel row, dz split once for three products) pays
 // for conv3 (0.047 -> 0.042 ms); for conv4 its 238 registers and 74 KB of LDS cost more than they save (0.111 -> 0.122 ms).
-template <int CIN, int COUT, int TPB>
-void launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s)
+template <int CIN, int COUT, int TPB, bool DPRE = false>
+void launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s, __bf16 *const *dz_planes = nullptr)
 {
     if (TPB != 1 && g.KW != TPB) { fail(KWS_ERR_UNSUPPORTED, "split-precision weight gradient expects a kernel %d taps wide", TPB); return; }
     constexpr size_t stage = (size_t)3 * 32 * 4 * (TPB * tr_row_words(CIN) + tr_row_words(COUT)), tile = (size_t)CIN * COUT * sizeof(float);
     constexpr size_t smem = stage > tile ? stage : tile;
     static const int occ = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT, TPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        return resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB>, 256, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        return resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE>, 256, smem);
     }();
     const long M = (long)g.B * g.Ho * g.Wo, nchunk = (M + 31) / 32;
     const int ngroups = g.KH * g.KW / TPB;
@@ -174,8 +176,9 @@ void launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeo
     nranges = std::min<long>(nranges, std::max<long>(8, (nchunk / 4 + 7) / 8 * 8));
     const int cpb = (int)((nchunk + nranges - 1) / nranges);
     static const std::string name = "conv_wgrad_bf16<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
-    KWS_LAUNCH(name.c_str(), (conv_wgrad_bf16_kernel<CIN, COUT, TPB>), dim3((unsigned)(nranges * ngroups)), dim3(256), smem, s, x, dz, dw,
-               zero_page(), g, cpb, (int)nranges);
+    const Bf16Planes dpl{{DPRE ? dz_planes[0] : nullptr, DPRE ? dz_planes[1] : nullptr, DPRE ? dz_planes[2] : nullptr}};
+    KWS_LAUNCH(name.c_str(), (conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE>), dim3((unsigned)(nranges * ngroups)), dim3(256), smem, s, x, dz, dw,
+               zero_page(), g, cpb, (int)nranges, dpl);
 }
 
 // dx <- dgrad(dz): ONE launch over every stride-parity class of the input pixels (blockIdx.y = class).  MW (16-row tiles
@@ -231,7 +234,7 @@ static int g_matrix_precision = 1;
 // returns the number of blocks that wrote BatchNorm partial sums (0: `partial` was not given or the grid exceeds its stride)
 template <int CR, int CO, int MODE, int EPI>
 int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], const float *bias, float *dst, const ConvGeom &g,
-                hipStream_t s, double *partial = nullptr, const float *shift = nullptr)
+                hipStream_t s, double *partial = nullptr, const float *shift = nullptr, __bf16 *const *src_planes = nullptr)
 {
     const long M = MODE == MODE_FWD ? (long)g.B * g.Ho * g.Wo : (long)g.B * g.H * g.W;
     static const std::string name = std::string(what) + "<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
@@ -245,6 +248,16 @@ int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], con
         KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, true>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, partial,
                    kStatStride);
         return (int)nblk;
+    }
+    if (src_planes) {                            // the A operand is already split (bn_bwd_apply_planes_kernel)
+        if constexpr ((32 * RT * 4) % 256 == 0) {
+            const Bf16Planes apl{{src_planes[0], src_planes[1], src_planes[2]}};
+            KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, false, true>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, nullptr,
+                       0, shift, apl);
+            return 0;
+        } else {
+            return fail(KWS_ERR_UNSUPPORTED, "pre-split operand planes need 64 rows per block");
+        }
     }
     KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, false>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, nullptr, 0, shift);
     return 0;
@@ -480,6 +493,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                    grads + m->o_g[l], grads + m->o_b[l], k);
         if (l == 1)
             ;                                                   // fused into conv_dgrad_clip's staging below
+        else if (l == 3 && g_matrix_precision == 1)
+            // split precision: dz4 leaves as bf16 h/m/l planes, which is what both of its consumers stage (no fp32 dz4)
+            KWS_LAUNCH(prof_name("bn_bwd_apply_planes_kernel", l + 1), bn_bwd_apply_planes_kernel<true>, dim3(blocks_for(M * C / 4, 256)), dim3(256), 0, s,
+                       w.z[l], w.gz[l], k, params + m->o_g[l], M * C / 4, C, (Bf16PlanesOut{{w.dzp[0], w.dzp[1], w.dzp[2]}}));
         else if (l == 3)
             KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_kernel<true>, dim3(blocks_for(M * C, 256)), dim3(256), 0, s, w.z[l], w.gz[l], k,
                        params + m->o_g[l], M * C, C);
@@ -493,7 +510,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
-            if (g_matrix_precision == 1) launch_wgrad_bf16<64, 128, 1>(in, w.gz[3], dk, g, s2);
+            if (g_matrix_precision == 1) launch_wgrad_bf16<64, 128, 1, true>(in, nullptr, dk, g, s2, w.dzp);
             else launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);
             if (bucket_event) {
                 // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here: it
@@ -502,7 +519,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                 // not wait for the conv4 wgrad.
                 KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
             }
-            if (g_matrix_precision == 1) launch_bf16<128, 64, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.gz[3], w.wsp[1], nullptr, w.da[2], g, s);
+            if (g_matrix_precision == 1) launch_bf16<128, 64, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", nullptr, w.wsp[1], nullptr, w.da[2], g, s, nullptr, nullptr, w.dzp);
             else launch_dgrad<128, 64, 1>(w.gz[3], kern, w.da[2], g, s);
         } else if (l == 2) {
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);

@@ -170,3 +170,48 @@ def test_eval_harness_confusion_matrix(torch):
     np.add.at(ref, (y, want), 1)
     assert cm.sum() == 700 and abs(acc - (want == y).mean()) < 0.01
     assert np.abs(cm - ref).sum() <= 4          # an untrained net has near-tied scores on a few clips
+
+
+@pytest.mark.parametrize("model_type,fp16", [("simple_cnn", False), ("simple_cnn_lite", False), ("simple_cnn_lite", True)])
+def test_inference_session_end_to_end_pcm16(torch, model_type, fp16):
+    """BASELINE configs[4] structure: PCM16 clips -> featurize + forward captured in ONE hipGraph (kws_amd.inference).
+    The replayed graph is bit-identical to the eager launches, and the whole chain agrees with the CPU oracle
+    (C featurizer + float64 model): probabilities within 1e-3, class index exact where the two best classes are 2e-3 apart."""
+    from classifier.params import pr
+    from kws_amd.featurizer import Featurizer
+    from kws_amd.inference import InferenceSession
+    from kws_amd.model import DeviceModel, ModelSpec
+    from oracle import featurizer_oracle as fo
+    from oracle import model_oracle as mo
+    B, C = 48, 36
+    om = mo.Model(model_type, C).init_weights(3)
+    rng = np.random.default_rng(4)
+    ws = om.get_weights()
+    for i, (li, n, t) in enumerate(om.weight_list()):
+        if n in ("gamma", "moving_variance"):
+            ws[i] = ws[i] * rng.uniform(0.5, 1.5, ws[i].shape)
+        elif n in ("beta", "bias", "moving_mean"):
+            ws[i] = ws[i] + 0.1 * rng.standard_normal(ws[i].shape)
+    om.set_weights(ws)
+    dm = DeviceModel(ModelSpec(model_type, C, pr.n_features, pr.feature_size))
+    dm.set_weights(om.get_weights())
+    pcm = np.clip(3000.0 * rng.standard_normal((B, 16000)), -32768, 32767).astype(np.int16)
+    feat = Featurizer(pr, "mel")
+    graph = InferenceSession(dm, feat, B, wav_dtype=torch.int16, use_graph=True, fp16=fp16)
+    eager = InferenceSession(dm, feat, B, wav_dtype=torch.int16, use_graph=False, fp16=fp16)
+    for s in (graph, eager):
+        s.wav.copy_(torch.from_numpy(pcm))
+    pg, ag = graph.run()
+    pg2, _ = graph.run()
+    pe, ae = eager.run()
+    torch.cuda.synchronize()
+    assert torch.equal(pg, pe) and torch.equal(ag, ae) and torch.equal(pg, pg2)
+    import kws_amd.lib as L
+    assert L.get_inference_precision() == L.INFER_FP32               # the session restores the library switch
+    x = fo.featurize_batch(pcm.astype(np.float32) / 32768.0)          # data_utils.py:21 scaling, then the CPU featurizer
+    want = om.predict(x.reshape(B, pr.n_features, pr.feature_size).astype(np.float64))
+    got = pg.cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=1e-3, rtol=0)
+    top2 = np.sort(want, axis=-1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2e-3
+    np.testing.assert_array_equal(ag.cpu().numpy()[clear], want.argmax(-1)[clear])

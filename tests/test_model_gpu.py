@@ -551,6 +551,33 @@ def test_bucket_event_marks_final_early_gradients(torch):
         assert float(snap.abs().sum()) > 0
 
 
+@pytest.mark.parametrize("model_type", ["simple_cnn", "simple_cnn_lite", "simple_gru"])
+def test_overlap_and_forward_events_are_recorded_in_order(torch, model_type):
+    """kws_train_args.overlap_event (behind the last forward convolution) and forward_event (behind the loss) are recorded on
+    the caller's stream by every model kind, overlap first; a side stream ordered behind overlap_event may overwrite the
+    NEXT batch's feature buffer while the step runs, and the step's results do not depend on the events being requested."""
+    C, B = 12, 256
+    om, dm = build(model_type, C)
+    x = torch.from_numpy(features(B, 8)).cuda()
+    y = torch.from_numpy(np.random.default_rng(9).integers(0, C, B).astype(np.int32)).cuda()
+    dm.train_fwd_bwd(x, y, dropout_seed=3)
+    torch.cuda.synchronize()
+    want = dm.grads.clone()
+    ov, fw = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    side = torch.cuda.Stream()
+    other = torch.zeros_like(x)
+    dm.train_fwd_bwd(x, y, dropout_seed=3, overlap_event=ov, forward_event=fw)
+    side.wait_event(ov)
+    with torch.cuda.stream(side):
+        other.add_(1.0)                                    # independent work ordered behind the event
+    torch.cuda.synchronize()
+    assert ov.query() and fw.query()
+    assert ov.elapsed_time(fw) >= 0.0                      # overlap_event is not later than forward_event
+    assert float(other.min()) == 1.0
+    got = dm.grads
+    assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-4      # float-atomic ordering only
+
+
 @pytest.mark.parametrize("model_type,nf,fs", [("simple_cnn", 29, 13), ("simple_cnn", 40, 24), ("simple_cnn", 24, 16), ("simple_cnn", 62, 21),
                                               ("simple_cnn_lite", 29, 13), ("simple_cnn_lite", 40, 24),
                                               ("simple_gru", 17, 13), ("simple_lstm", 23, 40)])

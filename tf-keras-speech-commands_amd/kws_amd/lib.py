@@ -36,7 +36,7 @@ class KwsTrainArgs(ctypes.Structure):
                 ("state", ctypes.c_void_p), ("grads", ctypes.c_void_p), ("ws", ctypes.c_void_p),
                 ("ws_bytes", ctypes.c_size_t), ("dropout_seed", ctypes.c_uint64), ("grad_scale", ctypes.c_float),
                 ("probs", ctypes.c_void_p), ("stats", ctypes.c_void_p), ("bucket_event", ctypes.c_void_p),
-                ("forward_event", ctypes.c_void_p)]
+                ("forward_event", ctypes.c_void_p), ("overlap_event", ctypes.c_void_p)]
 
 
 MODEL_KINDS = {"simple_cnn": 0, "simple_cnn_lite": 1, "simple_gru": 2, "simple_lstm": 3}

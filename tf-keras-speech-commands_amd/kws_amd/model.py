@@ -138,7 +138,7 @@ class DeviceModel(object):
         return probs, am
 
     def train_fwd_bwd(self, feat, labels, class_weights=None, dropout_seed=0, grad_scale=1.0, want_probs=False,
-                      ignore_index=0, bucket_event=None, forward_event=None):
+                      ignore_index=0, bucket_event=None, forward_event=None, overlap_event=None):
         """labels: CUDA int32 (B,); class_weights: CUDA float32 (C,) or None.  Leaves grads in self.grads and
         {sum of losses, top-1 hits} in self.stats (device).  bucket_event: torch.cuda.Event recorded when the early
         gradient bucket [grad_split, P) is final."""
@@ -157,11 +157,12 @@ class DeviceModel(object):
         a.dropout_seed, a.grad_scale = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, float(grad_scale)
         a.probs = probs.data_ptr() if want_probs else None
         a.stats = self.stats.data_ptr()
-        for ev in (bucket_event, forward_event):
+        for ev in (bucket_event, forward_event, overlap_event):
             if ev is not None and not ev.cuda_event:
                 ev.record()                     # torch creates the hipEvent_t lazily; an un-recorded Event has no handle yet
         a.bucket_event = bucket_event.cuda_event if bucket_event is not None else None
         a.forward_event = forward_event.cuda_event if forward_event is not None else None
+        a.overlap_event = overlap_event.cuda_event if overlap_event is not None else None
         _l.check(self._L.kws_model_train_fwd_bwd(self.spec.handle, ctypes.byref(a), torch.cuda.current_stream().cuda_stream))
         return probs
 

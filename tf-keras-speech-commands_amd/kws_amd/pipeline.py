@@ -24,8 +24,9 @@ class FeaturePipeline(object):
 
     def submit(self, wav, valid_len=None, after=None):
         """Enqueue the featurization of one batch on the side stream (returns at once).  `after`: an event on the main
-        stream to start behind (e.g. the running step's forward_event, so that the featurizer shares the chip with the
-        matrix-core-bound backward pass rather than with the forward pass); default: everything enqueued so far."""
+        stream to start behind -- best the running step's overlap_event (DeviceModel.train_fwd_bwd(overlap_event=...),
+        recorded behind the last forward convolution: measured 3.6 % faster per step than starting with the step and
+        2.7 % faster than starting at forward_event); default: everything enqueued so far."""
         torch = _torch()
         i = self.n_submitted % 2
         if after is not None:

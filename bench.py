@@ -119,8 +119,8 @@ def cpu_baseline(sample_clips, steps, n_classes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (weak scaling)")
     ap.add_argument("--cpu-clips", type=int, default=512)
     ap.add_argument("--cpu-steps", type=int, default=3)

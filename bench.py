@@ -163,6 +163,9 @@ def main():
     step_no = [0]
     overlap_ev = torch.cuda.Event()
 
+    def submit_next():
+        pipe.submit(wav, after=overlap_ev)
+
     def run_steps(n):
         # n complete train steps = n featurizations + n (fwd + bwd + all-reduce + Adam), all enqueued inside this call.
         # The features of batch k+1 are computed on a side stream while batch k trains (kws_amd/pipeline.py); the first
@@ -173,11 +176,11 @@ def main():
         for i in range(n):
             step_no[0] += 1
             feat = pipe.take()
-            dm.train_fwd_bwd(feat, labels, dropout_seed=step_no[0], grad_scale=1.0 / world, overlap_event=overlap_ev)
-            if i + 1 < n:
-                # next batch's features on the side stream, started behind this step's last forward convolution (the library
-                # records overlap_ev there): from that point the main chain is small kernels, then matrix-bound ones
-                pipe.submit(wav, after=overlap_ev)
+            # next batch's features on the side stream, started behind this step's last forward convolution: the library
+            # records overlap_ev there and calls back, so the featurizer launch also sits at that point in HOST order
+            # (from there the main chain is small kernels, then matrix-bound ones)
+            dm.train_fwd_bwd(feat, labels, dropout_seed=step_no[0], grad_scale=1.0 / world, overlap_event=overlap_ev,
+                             overlap_callback=submit_next if i + 1 < n else None)
             pipe.release()
             if dist is not None:
                 dist.all_reduce(dm.grads)      # RCCL sum over xGMI; 540 KB flat buffer

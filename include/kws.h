@@ -192,6 +192,11 @@ typedef struct kws_train_args {
                                    (the next batch's featurization): started there it costs the step 3.6 % less than started
                                    at the beginning of the step and 2.7 % less than at forward_event (B = 4096, same-box A/B).
                                    Recurrent models record it together with forward_event.                              */
+    void (*overlap_callback)(void *user);   /* NULL or a host function the call invokes (same thread, once) right after it has
+                                   enqueued the work overlap_event marks: enqueueing the next batch's kws_featurize from it
+                                   puts that launch at the same place in HOST order, so the overlap does not depend on how far
+                                   the host runs ahead of the device (under a tracing profiler it does not run ahead at all) */
+    void *overlap_user;
 } kws_train_args;
 int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream);
 /* Arithmetic of the GEMM-shaped layers with 32 or more reduced channels (simple_cnn: conv3, conv4, dense).

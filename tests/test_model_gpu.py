@@ -576,6 +576,22 @@ def test_overlap_and_forward_events_are_recorded_in_order(torch, model_type):
     assert float(other.min()) == 1.0
     got = dm.grads
     assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 1e-4      # float-atomic ordering only
+    # overlap_callback: a host function the call invokes once, right behind the work overlap_event marks (the event is already
+    # recorded in host order, so work enqueued from the callback can wait on it); exceptions come back to the caller
+    calls = []
+    ev2 = torch.cuda.Event()
+
+    def cb():
+        calls.append(1)
+        side.wait_event(ev2)
+        with torch.cuda.stream(side):
+            other.add_(1.0)
+    dm.train_fwd_bwd(x, y, dropout_seed=3, overlap_event=ev2, overlap_callback=cb)
+    torch.cuda.synchronize()
+    assert calls == [1] and float(other.min()) == 2.0
+    with pytest.raises(RuntimeError, match="from the callback"):
+        dm.train_fwd_bwd(x, y, dropout_seed=3, overlap_callback=lambda: (_ for _ in ()).throw(RuntimeError("from the callback")))
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("model_type,nf,fs", [("simple_cnn", 29, 13), ("simple_cnn", 40, 24), ("simple_cnn", 24, 16), ("simple_cnn", 62, 21),

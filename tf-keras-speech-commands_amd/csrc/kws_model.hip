@@ -289,7 +289,8 @@ ConvGeom geom3x3(int B, int H, int W, int stride)
 // zero_grads (training, split precision): the gradient buffer of the backward pass that follows is cleared on the side
 // stream beside the weight split instead of on the main chain; *zeroed tells the caller whether that happened
 int cnn_forward(const kws_model *m, const float *feat, int B, const float *params, float *state, CnnWs &w, bool training,
-                uint64_t seed, hipStream_t s, float *zero_grads = nullptr, bool *zeroed = nullptr, hipEvent_t overlap_event = nullptr)
+                uint64_t seed, hipStream_t s, float *zero_grads = nullptr, bool *zeroed = nullptr, hipEvent_t overlap_event = nullptr,
+                void (*overlap_cb)(void *) = nullptr, void *overlap_user = nullptr)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};   // conv input sizes
@@ -401,6 +402,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         // behind the last convolution: from here to BN4's backward the main chain is small kernels (activation, dense, head),
         // the best place for the caller to start the next batch's featurizer (kws_train_args.overlap_event)
         if (l == 3 && overlap_event) KWS_HIP_CHECK(hipEventRecord(overlap_event, s));
+        if (l == 3 && overlap_cb) overlap_cb(overlap_user);
         if (pool[l]) {
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
@@ -978,9 +980,10 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     bool grads_zeroed = false;     // cleared beside the weight split (the main chain joins that branch before conv3)
     rc = lite ? lite_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s)
               : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s, a->grads, &grads_zeroed,
-                            static_cast<hipEvent_t>(a->overlap_event));
+                            static_cast<hipEvent_t>(a->overlap_event), a->overlap_callback, a->overlap_user);
     if (rc) return rc;
     if (lite && a->overlap_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->overlap_event), s));
+    if (lite && a->overlap_callback) a->overlap_callback(a->overlap_user);
     // Keras reduces the per-sample losses with a batch mean (train.py:75-77): d(mean)/d(logits) carries 1/B
     // simple_cnn: the head's backward kernel also sums the per-sample losses (no separate loss_reduce launch)
     const bool fuse_stats = !lite && head_bwd_fuses(m);

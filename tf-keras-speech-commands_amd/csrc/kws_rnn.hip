@@ -150,6 +150,7 @@ int gru_train_fwd_bwd(kws_model *m, const kws_train_args *a, hipStream_t s)
                   a->grad_scale / (float)a->B, a->stats, a->ignore_index, s);
     if (rc) return rc;
     if (a->overlap_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->overlap_event), s));
+    if (a->overlap_callback) a->overlap_callback(a->overlap_user);
     if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
     KWS_HIP_CHECK(hipMemsetAsync(a->grads, 0, sizeof(float) * (size_t)m->P, s));
     rc = run_head_bwd(m, a->B, a->params, w.h_last, w.dlogits, w.dh_last, a->grads, false, s);

@@ -30,13 +30,17 @@ class KwsTensorInfo(ctypes.Structure):
                 ("trainable", ctypes.c_int32), ("offset", ctypes.c_int64), ("size", ctypes.c_int64)]
 
 
+OVERLAP_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p)     # kws_train_args.overlap_callback
+
+
 class KwsTrainArgs(ctypes.Structure):
     _fields_ = [("feat", ctypes.c_void_p), ("labels", ctypes.c_void_p), ("class_weights", ctypes.c_void_p),
                 ("B", ctypes.c_int32), ("ignore_index", ctypes.c_int32), ("params", ctypes.c_void_p),
                 ("state", ctypes.c_void_p), ("grads", ctypes.c_void_p), ("ws", ctypes.c_void_p),
                 ("ws_bytes", ctypes.c_size_t), ("dropout_seed", ctypes.c_uint64), ("grad_scale", ctypes.c_float),
                 ("probs", ctypes.c_void_p), ("stats", ctypes.c_void_p), ("bucket_event", ctypes.c_void_p),
-                ("forward_event", ctypes.c_void_p), ("overlap_event", ctypes.c_void_p)]
+                ("forward_event", ctypes.c_void_p), ("overlap_event", ctypes.c_void_p),
+                ("overlap_callback", OVERLAP_CB), ("overlap_user", ctypes.c_void_p)]
 
 
 MODEL_KINDS = {"simple_cnn": 0, "simple_cnn_lite": 1, "simple_gru": 2, "simple_lstm": 3}

@@ -138,7 +138,7 @@ class DeviceModel(object):
         return probs, am
 
     def train_fwd_bwd(self, feat, labels, class_weights=None, dropout_seed=0, grad_scale=1.0, want_probs=False,
-                      ignore_index=0, bucket_event=None, forward_event=None, overlap_event=None):
+                      ignore_index=0, bucket_event=None, forward_event=None, overlap_event=None, overlap_callback=None):
         """labels: CUDA int32 (B,); class_weights: CUDA float32 (C,) or None.  Leaves grads in self.grads and
         {sum of losses, top-1 hits} in self.stats (device).  bucket_event: torch.cuda.Event recorded when the early
         gradient bucket [grad_split, P) is final."""
@@ -163,7 +163,18 @@ class DeviceModel(object):
         a.bucket_event = bucket_event.cuda_event if bucket_event is not None else None
         a.forward_event = forward_event.cuda_event if forward_event is not None else None
         a.overlap_event = overlap_event.cuda_event if overlap_event is not None else None
+        raised = []
+        if overlap_callback is not None:           # host function called behind the last forward convolution (see include/kws.h)
+            def _cb(_user):
+                try:
+                    overlap_callback()
+                except BaseException as e:         # an exception must not unwind through the C frame
+                    raised.append(e)
+            cb = _l.OVERLAP_CB(_cb)
+            a.overlap_callback = cb
         _l.check(self._L.kws_model_train_fwd_bwd(self.spec.handle, ctypes.byref(a), torch.cuda.current_stream().cuda_stream))
+        if raised:
+            raise raised[0]
         return probs
 
     @property

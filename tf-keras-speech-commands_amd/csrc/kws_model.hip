@@ -557,8 +557,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (int rc = fork(1)) return rc;
             if (g_matrix_precision == 1 && H1 * W1 <= 160) {
                 const size_t smwb = std::max((size_t)3 * 32 * (H1 + 2) * (W1 + 2) + (size_t)6 * 32 * (H1 * W1 + 1), sizeof(float) * 9 * 16 * 32);
+                // two blocks per CU although three fit: the third takes the LDS the layer-1 kernels of the main chain need beside it
+                // (same-box A/B: 0.785 ms/step with one or two, 0.800 with three)
                 static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel, 256, smwb);
-                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel, dim3(even_grid(cu_count() * std::min(occ, 3))), dim3(256), smwb, s2, in,
+                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel, dim3(even_grid(cu_count() * std::min(occ, 2))), dim3(256), smwb, s2, in,
                            w.gz[1], dk, B, H1, W1);
             } else
                 KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);

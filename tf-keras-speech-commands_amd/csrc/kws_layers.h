@@ -38,14 +38,14 @@ __device__ __forceinline__ double wave_sum_partials(const double *__restrict__ p
 {
     const double *p = partial + ((long)which * C + c) * kStatStride;
     const int lane = threadIdx.x & 63;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (int b = lane; b < nblk; b += 256) {
-        s0 += p[b];
-        s1 += b + 64 < nblk ? p[b + 64] : 0.0;
-        s2 += b + 128 < nblk ? p[b + 128] : 0.0;
-        s3 += b + 192 < nblk ? p[b + 192] : 0.0;
-    }
-    double s = (s0 + s1) + (s2 + s3);
+    // all kStatStride / 64 = 16 loads of a lane are issued before the first add: one memory round trip instead of four
+    // dependent ones (these kernels are nothing but latency)
+    double v[kStatStride / 64];
+#pragma unroll
+    for (int j = 0; j < kStatStride / 64; ++j) v[j] = lane + 64 * j < nblk ? p[lane + 64 * j] : 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < kStatStride / 64; ++j) s += v[j];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     return s;

@@ -181,7 +181,8 @@ def main():
             # (from there the main chain is small kernels, then matrix-bound ones)
             dm.train_fwd_bwd(feat, labels, dropout_seed=step_no[0], grad_scale=1.0 / world, overlap_event=overlap_ev,
                              overlap_callback=submit_next if i + 1 < n else None)
-            pipe.release()
+            # no pipe.release() here: the featurizer that rewrites this step's feature buffer (batch k+2) is ordered behind the NEXT
+            # step's overlap event on this stream, i.e. behind every kernel of this step -- the extra event would cost 6 us per step
             if dist is not None:
                 dist.all_reduce(dm.grads)      # RCCL sum over xGMI; 540 KB flat buffer
             dm.adam_step(1e-3)

@@ -186,11 +186,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
 struct SplitDesc { const float *w; __bf16 *o[3], *t[3]; int taps, ci, co; };
 struct SplitDescs { SplitDesc d[4]; };
 
-__global__ __launch_bounds__(256) void weight_split_kernel(SplitDescs all)
+// one x-slice (bx of nbx) of descriptor d
+__device__ __forceinline__ void weight_split_slice(const SplitDesc &d, int bx, int nbx)
 {
-    const SplitDesc d = all.d[blockIdx.y];
     const int per = d.ci * d.co, total = d.taps * per;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < total; i += nbx * 256) {
         const float v = d.w[i];
         const __bf16 h = (__bf16)v;
         const float r1 = v - (float)h;
@@ -200,6 +200,11 @@ __global__ __launch_bounds__(256) void weight_split_kernel(SplitDescs all)
         d.o[0][i] = h; d.o[1][i] = m; d.o[2][i] = l;
         d.t[0][t] = h; d.t[1][t] = m; d.t[2][t] = l;
     }
+}
+
+__global__ __launch_bounds__(256) void weight_split_kernel(SplitDescs all)
+{
+    weight_split_slice(all.d[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 struct Bf16Planes { const __bf16 *p[3]; };

@@ -362,8 +362,8 @@ __device__ __forceinline__ void l1m_reduce_store(double s0, double s1, double *_
     }
 }
 
-__global__ __launch_bounds__(256) void l1m_stats_kernel(const float *__restrict__ feat, const float *__restrict__ wk, int B, int H,
-                                                         int W, int clips_per_wave, double *__restrict__ partial)
+__device__ __forceinline__ void l1m_stats_body(const float *__restrict__ feat, const float *__restrict__ wk, int B, int H, int W,
+                                               int clips_per_wave, double *__restrict__ partial)
 {
     extern __shared__ float l1smem[];
     const int lq = (threadIdx.x & 63) >> 4;
@@ -390,6 +390,12 @@ __global__ __launch_bounds__(256) void l1m_stats_kernel(const float *__restrict_
         ss += (double)fss;
     }
     l1m_reduce_store(s, ss, partial);
+}
+
+__global__ __launch_bounds__(256) void l1m_stats_kernel(const float *__restrict__ feat, const float *__restrict__ wk, int B, int H,
+                                                         int W, int clips_per_wave, double *__restrict__ partial)
+{
+    l1m_stats_body(feat, wk, B, H, W, clips_per_wave, partial);
 }
 
 __global__ __launch_bounds__(256) void l1m_act_pool_kernel(const float *__restrict__ feat, const float *__restrict__ wk,

@@ -264,6 +264,17 @@ int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], con
 }
 
 // h/m/l bf16 planes of the three GEMM weight tensors, once per step (one launch)
+static SplitDescs split_descs(const kws_model *m, const float *params, CnnWs &w)
+{
+    SplitDescs all{};
+    const float *src[3] = {params + m->o_k[2], params + m->o_k[3], params + m->o_dk};
+    const int taps[3] = {9, 9, m->d.H4 * m->d.W4}, ci[3] = {32, 64, 128}, co[3] = {64, 128, 128};
+    for (int t = 0; t < 3; ++t)
+        all.d[t] = SplitDesc{src[t], {w.wsp[t][0], w.wsp[t][1], w.wsp[t][2]}, {w.wsp[t][3], w.wsp[t][4], w.wsp[t][5]}, taps[t], ci[t], co[t]};
+    all.d[3] = all.d[2];
+    return all;
+}
+
 static int split_weights(const kws_model *m, const float *params, CnnWs &w, hipStream_t s)
 {
     SplitDescs all{};
@@ -285,6 +296,22 @@ ConvGeom geom3x3(int B, int H, int W, int stride)
     return g;
 }
 
+// First kernel of a training forward pass in split precision: the layer-1 statistics blocks, and behind them in the SAME grid
+// 48 blocks that split the conv3 / conv4 / dense weights into their bf16 planes and 16 that clear the gradient buffer.  Both
+// jobs used to run on the side stream behind an event and were joined before conv3: two events on the main chain (6-8 us
+// each) for 12 us of work that hides under the statistics pass.
+constexpr int kPrepSplitBlocks = 16, kPrepZeroBlocks = 16, kPrepBlocks = 3 * kPrepSplitBlocks + kPrepZeroBlocks;
+__global__ __launch_bounds__(256) void l1m_stats_prep_kernel(const float *__restrict__ feat, const float *__restrict__ wk, int B, int H, int W,
+                                                              int clips_per_wave, double *__restrict__ partial, int nstat, SplitDescs all,
+                                                              float *__restrict__ zero_buf, long zero_n)
+{
+    if ((int)blockIdx.x < nstat) { l1m_stats_body(feat, wk, B, H, W, clips_per_wave, partial); return; }
+    const int e = blockIdx.x - nstat;
+    if (e < 3 * kPrepSplitBlocks) { weight_split_slice(all.d[e / kPrepSplitBlocks], e % kPrepSplitBlocks, kPrepSplitBlocks); return; }
+    if (zero_buf)
+        for (long i = (long)(e - 3 * kPrepSplitBlocks) * 256 + threadIdx.x; i < zero_n; i += (long)kPrepZeroBlocks * 256) zero_buf[i] = 0.f;
+}
+
 // ---- forward ------------------------------------------------------------------------------------------------
 // zero_grads (training, split precision): the gradient buffer of the backward pass that follows is cleared on the side
 // stream beside the weight split instead of on the main chain; *zeroed tells the caller whether that happened
@@ -299,7 +326,13 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
 
     const bool bf16 = g_matrix_precision == 1;
-    if (bf16 && training) {
+    // training in split precision at a geometry the MFMA layer-1 kernels cover: the weight split and the gradient clear ride
+    // in the grid of the layer-1 statistics kernel (l1m_stats_prep_kernel) -- no side-stream branch, no events
+    const bool prep_in_stats = bf16 && training && d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * kL1Stage &&
+                               (d.H0 / 2) * (d.W0 / 2) <= 4 * kL1MaxTiles;
+    if (prep_in_stats) {
+        if (zero_grads && zeroed) *zeroed = true;
+    } else if (bf16 && training) {
         // the h/m/l planes are first needed by conv3: split on the side stream beside layers 1-2, join before conv3
         hipStream_t s2 = side_stream();
         if (!s2) return fail(KWS_ERR_HIP, "cannot create the internal side stream");
@@ -331,7 +364,10 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         BnCoef k1 = coef_of(w.coef[0], 16);
         const float *kern1 = params + m->o_k[0];
         if (training) {
-            if (l1m) KWS_LAUNCH("l1m_stats_kernel", l1m_stats_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, B, d.H0, d.W0, cpw, w.partial);
+            if (l1m && prep_in_stats)
+                KWS_LAUNCH("l1m_stats_kernel", l1m_stats_prep_kernel, dim3(nbm + kPrepBlocks), dim3(256), smemm, s, feat, kern1, B, d.H0, d.W0, cpw, w.partial,
+                           nbm, split_descs(m, params, w), zero_grads, (long)m->P);
+            else if (l1m) KWS_LAUNCH("l1m_stats_kernel", l1m_stats_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, B, d.H0, d.W0, cpw, w.partial);
             else KWS_LAUNCH("l1_stats_kernel", l1_stats_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, B, d.H0, d.W0, cpb, w.partial);
             KWS_LAUNCH(prof_name("bn_finalize_train_kernel", 1), bn_finalize_train_kernel, dim3(16), dim3(64), 0, s, w.partial, l1m ? nbm : nb, M1, 16,
                        params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1);
@@ -378,7 +414,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             launch_bf16<32, 64, MODE_FWD, EPI_BN_RELU6>("conv_bf16_fwd_bn", in, w.wsp[0], k3.scale, w.a[2], geom3x3(B, Hs[2], Ws[2], 2), s, nullptr, k3.shift);
             continue;
         } else if (l == 2) {
-            if (bf16 && training) KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(11), 0));     // the weight planes are ready
+            if (bf16 && training && !prep_in_stats) KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(11), 0));     // the weight planes are ready
             // the split-precision kernels write the BatchNorm partial sums from their epilogue when training
             if (bf16) fused_stat_blocks = launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s,
                                                                                 training ? w.partial : nullptr);

@@ -33,7 +33,8 @@ typedef enum kws_status {
     KWS_ERR_UNSUPPORTED = -2, /* valid in the reference, not built here yet      */
     KWS_ERR_HIP = -3,         /* HIP runtime error (no device, launch failure)   */
     KWS_ERR_NOMEM = -4,
-    KWS_ERR_WORKSPACE = -5    /* caller's workspace too small                    */
+    KWS_ERR_WORKSPACE = -5,   /* caller's workspace too small                    */
+    KWS_ERR_COMM = -6         /* RCCL missing or a collective failed             */
 } kws_status;
 
 const char *kws_version(void);
@@ -204,11 +205,13 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
  *                      leading partial products on the bf16 matrix cores with fp32 accumulation: fp32-level error at
  *                      ~2.7x the fp32 matrix rate
  *   KWS_MATRIX_FP32:   the fp32 MFMA everywhere (bit-identical to an fp32 fmaf chain)
- * Library-wide; takes effect at the next forward / train call. */
+ * kws_set_matrix_precision sets the library-wide DEFAULT, which a model follows until kws_model_set_precision gives it its own
+ * value; read at the next forward / train call. */
 enum { KWS_MATRIX_FP32 = 0, KWS_MATRIX_BF16X6 = 1 };
 int kws_set_matrix_precision(int mode);
 int kws_get_matrix_precision(void);
-/* Precision of simple_cnn_lite INFERENCE (kws_model_forward; BASELINE configs[4] asks fp16).  Library-wide switch.
+/* Precision of simple_cnn_lite INFERENCE (kws_model_forward; BASELINE configs[4] asks fp16).  Library-wide default, per model
+ * through kws_model_set_precision.
  *   KWS_INFER_FP32 (default): fp32 activations and products.
  *   KWS_INFER_FP16: the activations between stages and every matrix operand are fp16, all accumulation (depthwise taps,
  *                   matrix products, bias / BatchNorm affine, softmax) fp32; the network behind the second pooling stage
@@ -218,9 +221,62 @@ int kws_get_matrix_precision(void);
 enum { KWS_INFER_FP32 = 0, KWS_INFER_FP16 = 1 };
 int kws_set_inference_precision(int mode);
 int kws_get_inference_precision(void);
+/* Per-model precision attributes: `matrix` in {KWS_MATRIX_FP32, KWS_MATRIX_BF16X6}, `infer` in {KWS_INFER_FP32, KWS_INFER_FP16},
+ * or -1 = follow the library-wide default above.  Two models with different precisions may live in one process (one host
+ * thread per model; a model's calls are not re-entrant).  kws_model_get_precision reports the EFFECTIVE values. */
+int kws_model_set_precision(kws_model *m, int matrix, int infer);
+int kws_model_get_precision(const kws_model *m, int *matrix, int *infer);
+/* Test aid: with on != 0 every weight-gradient reduction of simple_cnn / simple_cnn_lite runs in a fixed order (one block
+ * along the reduced axis, a batch-ordered head kernel) instead of per-block float atomics, so two runs of a step give
+ * bit-identical gradients.  Much slower at large batches; recurrent models: KWS_ERR_UNSUPPORTED. */
+int kws_model_set_deterministic(kws_model *m, int on);
 
 /* offset (in floats) that splits `grads` into {late bucket [0, split), early bucket [split, param_count)} */
 int64_t kws_model_grad_split(const kws_model *m);
+
+/* ------------------------------------------------------------------------
+ * Data-parallel exchange (RCCL over xGMI).  New: the reference trains in one
+ * process (train.py:81-92, model.fit(..., workers=1) at :90-91); this is the
+ * collective SURVEY.md section 5 / 8(e) specify around that loop.  One process
+ * per GPU, one communicator per process, created on the CURRENT device.
+ * RCCL is bound at run time (dlopen of librccl.so.1, sharing the instance the
+ * process already holds if any), so single-GPU hosts never load it.
+ *
+ *   rank 0:  kws_comm_unique_id(id);  ship the 128 bytes to every rank (file, socket, MPI, torch.distributed ...)
+ *   all:     kws_comm_init(rank, world, id, &comm)            -- collective
+ *   step:    kws_model_train_fwd_bwd(..., bucket_event ...);  grad_scale = local clips / global clips
+ *            kws_allreduce_grads(comm, grads, P, kws_model_grad_split(m), bucket_event, state, S, weight, stream);
+ *            kws_adam_step(...)
+ * ---------------------------------------------------------------------- */
+typedef struct kws_comm kws_comm;
+#define KWS_COMM_ID_BYTES 128
+int kws_comm_unique_id(void *id /* KWS_COMM_ID_BYTES host bytes */);
+int kws_comm_init(int rank, int world, const void *unique_id, kws_comm **out);
+void kws_comm_destroy(kws_comm *c);
+/* rccl_version: NCCL-style code of the bound library (e.g. 22707), 0 if unknown; any out pointer may be NULL */
+int kws_comm_info(const kws_comm *c, int *rank, int *world, int *rccl_version);
+
+/* In-place sum over ranks of the flat gradient buffer `grads` (n floats), as two buckets on the communicator's own
+ * high-priority stream:
+ *   early  grads[split, n)  starts as soon as `bucket_event` (kws_train_args.bucket_event of the step just enqueued) fires,
+ *                           i.e. while the rest of the backward pass still runs on `stream`;
+ *   late   grads[0, split)  behind everything enqueued on `stream` so far, grouped with the sum of
+ *          state[0, n_state) * state_weight  (BatchNormalization moving statistics: weight = local clips / global clips
+ *                           gives their batch-weighted mean over the replicas; n_state = 0 skips it).
+ * `stream` then waits for the communicator's stream, so the optimizer step may be enqueued on it right away.
+ * bucket_event == NULL or split in {0, n}: one bucket, no overlap.  world == 1 runs the same code path. */
+int kws_allreduce_grads(kws_comm *c, float *grads, int64_t n, int64_t split, void *bucket_event, float *state, int64_t n_state,
+                        float state_weight, void *stream);
+
+/* A plain in-place all-reduce ordered with `stream` on both sides (loss / hit counters of a logging step, timing maxima). */
+enum { KWS_DT_F32 = 0, KWS_DT_F64 = 1, KWS_DT_I32 = 2, KWS_DT_I64 = 3 };
+enum { KWS_OP_SUM = 0, KWS_OP_MAX = 1, KWS_OP_AVG = 2 };
+int kws_comm_allreduce(kws_comm *c, void *buf, int64_t n, int dtype, int op, void *stream);
+
+/* Opt-in timing of the two buckets of the most recent kws_allreduce_grads (HIP events on the communicator's stream);
+ * kws_comm_last_us synchronises those events; -1 = that bucket was not issued / timing off. */
+int kws_comm_timing(kws_comm *c, int on);
+int kws_comm_last_us(kws_comm *c, float *early_us, float *late_us);
 
 /* Standalone losses of classifier/loss.py: y_pred (B, C) probabilities (or logits when from_logits != 0),
  * labels (B) -> per-sample losses (B), exactly what the two classes' __call__ return. */

@@ -25,6 +25,62 @@ def _free_port():
     return p
 
 
+def _worker_uneven(rank, world, port, B, out_dir):
+    """Global batches that do not split evenly (7 -> 4 + 3; 1 -> 1 + 0): each rank scales the gradient of its LOCAL
+    mean loss by shard_plan's weight = local / global, an empty shard contributes zeros, and the BatchNormalization
+    moving statistics are averaged with the same weights (what KWSModel.fit does per step)."""
+    for p in (ROOT, os.path.join(ROOT, "tf-keras-speech-commands_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kws_amd.parallel import DataParallel
+    from oracle import model_oracle as mo
+    dp = DataParallel()
+    C = 4
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((B, 30, 20)) * 2
+    y = rng.integers(0, C, B)
+    m = mo.Model("simple_gru", C).init_weights(1)
+    lo, hi, weight = dp.shard_plan(B)
+    assert abs(weight - (hi - lo) / B) < 1e-15
+    n = m.trainable_count()
+    if hi > lo:
+        mo.train_forward_backward(m, x[lo:hi], y[lo:hi])
+        flat = np.concatenate([g.reshape(-1) for g in m.grad_list()]) * weight
+    else:
+        flat = np.zeros(n)
+    g = torch.from_numpy(flat.copy())
+    state = torch.full((6,), float(rank + 1), dtype=torch.float64)     # stand-in for this replica's moving statistics
+    dp.sync_grads(g, g.numel() // 3, None, state=state, state_weight=weight)
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), g.numpy())
+    np.save(os.path.join(out_dir, "st%d.npy" % rank), state.numpy())
+    np.save(os.path.join(out_dir, "w%d.npy" % rank), np.array([weight]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [7, 1])
+def test_uneven_shards_give_the_global_mean_gradient(tmp_path, B):
+    from oracle import model_oracle as mo
+    world = 2
+    mp.spawn(_worker_uneven, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = np.load(os.path.join(tmp_path, "g0.npy")), np.load(os.path.join(tmp_path, "g1.npy"))
+    np.testing.assert_array_equal(g0, g1)
+    C = 4
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((B, 30, 20)) * 2
+    y = rng.integers(0, C, B)
+    m = mo.Model("simple_gru", C).init_weights(1)
+    mo.train_forward_backward(m, x, y)
+    full = np.concatenate([g.reshape(-1) for g in m.grad_list()])
+    np.testing.assert_allclose(g0, full, atol=1e-12)      # NOT the plain mean of the two local gradients
+    w = [float(np.load(os.path.join(tmp_path, "w%d.npy" % r))[0]) for r in range(world)]
+    assert abs(sum(w) - 1.0) < 1e-15 and (B != 1 or w == [1.0, 0.0])
+    st0, st1 = np.load(os.path.join(tmp_path, "st0.npy")), np.load(os.path.join(tmp_path, "st1.npy"))
+    np.testing.assert_array_equal(st0, st1)
+    np.testing.assert_allclose(st0, w[0] * 1.0 + w[1] * 2.0, atol=1e-15)
+
+
 def _worker(rank, world, port, model_type, out_dir):
     for p in (ROOT, os.path.join(ROOT, "tf-keras-speech-commands_amd")):
         if p not in sys.path:
@@ -46,7 +102,7 @@ def _worker(rank, world, port, model_type, out_dir):
     flat = np.concatenate([g.reshape(-1) for g in m.grad_list()]) * dp.grad_scale
     g = torch.from_numpy(flat.copy())
     split = g.numel() // 3
-    dp.sync_grads(g, split, None)                        # CPU tensors: single all-reduce path
+    dp.sync_grads(g, split, None)                        # CPU tensors: the two buckets in order, no side stream
     stats = torch.tensor([loss * (hi - lo), float(hi - lo)], dtype=torch.float64)
     dp.sum_(stats)
     state = torch.full((4,), float(rank))

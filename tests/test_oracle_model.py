@@ -7,84 +7,13 @@ import torch
 import torch.nn.functional as F
 
 from oracle import model_oracle as mo
+from oracle import torch_ref as tr
 
-
-
-def tf_same_conv(x, w, stride):
-    """x NHWC, w HWIO -> NHWC, TF SAME padding (extra pad at bottom/right)."""
-    B, H, W, C = x.shape
-    kh, kw = w.shape[:2]
-    _, pt, pb = mo.same_pad(H, kh, stride)
-    _, pl, pr = mo.same_pad(W, kw, stride)
-    xt = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
-    return F.conv2d(xt, w.permute(3, 2, 0, 1), stride=stride).permute(0, 2, 3, 1)
 
 
 def torch_forward(model_type, ws, x, training, drop_mask=None):
-    """ws: list of torch tensors in Keras get_weights() order."""
-    it = iter(ws)
-    nxt = lambda: next(it)
-    if model_type in ("simple_cnn", "simple_cnn_lite"):
-        lite = model_type == "simple_cnn_lite"
-        h = x[..., None] if x.dim() == 3 else x
-        cfg = [(1, 16, 1, False, True), (16, 32, 1, False, True), (32, 64, 2, lite, False), (64, 128, 1, True, True)]
-        for cin, cout, s, relu, pool in cfg:
-            if lite:
-                dw, pw, b = nxt(), nxt(), nxt()
-                B, H, W, C = h.shape
-                _, pt, pb = mo.same_pad(H, 3, s)
-                _, pl, pr = mo.same_pad(W, 3, s)
-                ht = F.pad(h.permute(0, 3, 1, 2), (pl, pr, pt, pb))
-                ht = F.conv2d(ht, dw.permute(2, 3, 0, 1), stride=s, groups=cin)
-                h = F.conv2d(ht, pw.permute(3, 2, 0, 1)).permute(0, 2, 3, 1) + b
-            else:
-                h = tf_same_conv(h, nxt(), s)
-            if relu:
-                h = F.relu(h)
-            g, bt, mm, mv = nxt(), nxt(), nxt(), nxt()
-            if training:
-                flat = h.reshape(-1, cout)
-                mean, var = flat.mean(0), flat.var(0, unbiased=False)
-            else:
-                mean, var = mm, mv
-            h = (h - mean) / torch.sqrt(var + 1e-3) * g + bt
-            h = torch.clamp(h, 0, 6)
-            if pool:
-                h = F.max_pool2d(h.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
-        h = h.reshape(h.shape[0], -1)
-        if training and drop_mask is not None:
-            h = h * drop_mask
-        k, b = nxt(), nxt()
-        h = torch.clamp(h @ k + b, 0, 6)
-    elif model_type == "simple_gru":
-        k, rk, b = nxt(), nxt(), nxt()
-        u = rk.shape[0]
-        xx = x[..., 0] if x.dim() == 4 else x
-        if training and drop_mask is not None:
-            xx = xx * drop_mask[:, None, :]
-        h = torch.zeros((xx.shape[0], u), dtype=torch.float64)
-        for t in range(xx.shape[1]):
-            mx = xx[:, t] @ k + b[0]
-            mh = h @ rk + b[1]
-            z = torch.sigmoid(mx[:, :u] + mh[:, :u])
-            r = torch.sigmoid(mx[:, u:2 * u] + mh[:, u:2 * u])
-            hh = mx[:, 2 * u:] + r * mh[:, 2 * u:]
-            h = z * h + (1 - z) * hh
-    elif model_type == "simple_lstm":
-        k, rk, b = nxt(), nxt(), nxt()
-        u = rk.shape[0]
-        xx = x[..., 0] if x.dim() == 4 else x
-        if training and drop_mask is not None:
-            xx = xx * drop_mask[:, None, :]
-        h = torch.zeros((xx.shape[0], u), dtype=torch.float64)
-        c = torch.zeros((xx.shape[0], u), dtype=torch.float64)
-        for t in range(xx.shape[1]):
-            a = xx[:, t] @ k + h @ rk + b
-            i, f, g, o = torch.sigmoid(a[:, :u]), torch.sigmoid(a[:, u:2 * u]), torch.tanh(a[:, 2 * u:3 * u]), torch.sigmoid(a[:, 3 * u:])
-            c = f * c + i * g
-            h = o * torch.tanh(c)
-    k, b = nxt(), nxt()
-    return h @ k + b
+    """the torch-operator restatement (oracle/torch_ref.py: conv2d, F.batch_norm, max_pool2d, hand-written GRU / LSTM cells)"""
+    return tr.forward(model_type, ws, x, training, drop_mask)
 
 
 def make(model_type, C=6, seed=0, B=8):
@@ -166,6 +95,36 @@ def test_bn_moving_stats_update():
     n = flat.shape[0]
     np.testing.assert_allclose(bn.moving_mean, mm0 * 0.99 + flat.mean(0) * 0.01, atol=1e-12)
     np.testing.assert_allclose(bn.moving_variance, mv0 * 0.99 + flat.var(0) * n / (n - 1) * 0.01, atol=1e-12)
+
+
+@pytest.mark.parametrize("model_type,weighted", [("simple_cnn", False), ("simple_cnn", True), ("simple_cnn_lite", False), ("simple_gru", False),
+                                                 ("simple_lstm", False)])
+def test_multi_step_training_vs_torch_reference(model_type, weighted):
+    """Six optimizer steps of the numpy oracle against oracle/torch_ref.py, which shares no code with it: torch's own
+    F.batch_norm updates the moving statistics (momentum 0.99, epsilon 1e-3, unbiased variance), autograd supplies the
+    gradients and a hand-written Keras-form Adam (epsilon outside the bias correction) the update.  Loss per step, every
+    trainable tensor and every moving statistic agree to float64 rounding."""
+    C, B = 6, 12
+    m, _, _ = make(model_type, C, seed=4, B=B)
+    flags = [t for _, _, t in m.weight_list()]
+    tm = tr.TorchModel(model_type, m.get_weights(), flags)
+    opt_np, opt_t = mo.Adam(1e-3), tr.KerasAdam(1e-3)
+    rng = np.random.default_rng(21)
+    cw = np.array([0.3] + [0.7 / (C - 1)] * (C - 1)) if weighted else None
+    rate, width = (0.5, 256) if "cnn" in model_type else (0.2, 20)
+    for step in range(6):
+        x = rng.standard_normal((B, 30, 20)) * 3.0
+        y = rng.integers(0, C, B)
+        mask = (rng.uniform(size=(B, width)) >= rate) / (1 - rate)
+        loss_np, _, p_np = mo.train_forward_backward(m, x, y, cw, dropout_mask=mask)
+        m.set_trainable(opt_np.step(m.trainable_list(), m.grad_list()))
+        loss_t, p_t, _ = tm.train_step(opt_t, x, y, cw, mask)
+        assert abs(loss_np - loss_t) < 1e-10, (step, loss_np, loss_t)
+        np.testing.assert_allclose(p_np, p_t.numpy(), atol=1e-10)
+    for a, b, (li, n, t) in zip(m.get_weights(), tm.get_weights(), m.weight_list()):
+        np.testing.assert_allclose(a, b, atol=1e-9, rtol=1e-9, err_msg="layer %d %s after 6 steps" % (li, n))
+    x = rng.standard_normal((B, 30, 20)) * 3.0
+    np.testing.assert_allclose(m.predict(x), tm.predict(x), atol=1e-10)     # inference with the updated moving statistics
 
 
 def test_cross_entropy_clip_edges():

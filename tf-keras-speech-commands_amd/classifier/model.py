@@ -214,17 +214,29 @@ class KWSModel(object):
             dm.sgd_step(lr)
         opt.iterations += 1
 
-    def _train_batch(self, dm, dp, xb, yb, is_audio, cw, ignore_index, seed):
+    def _train_batch(self, dm, dp, xb, yb, is_audio, cw, ignore_index, seed, weight=None):
+        """One step.  Data parallel: `weight` = this rank's share of the global batch (DataParallel.shard_plan): the
+        gradient of the local mean loss is scaled by it, so the summed gradient is the global-batch mean the reference
+        computes (train.py:81-92) even when the last batch splits unevenly; a rank whose shard is empty contributes
+        zeros.  The BatchNormalization moving statistics are averaged with the same weights in the same exchange."""
         import torch
-        feat = self._features_of(xb, is_audio)
         if dp is not None and dp.active:
             ev = self._bucket_event
-            dm.train_fwd_bwd(feat, yb, cw, dropout_seed=seed, grad_scale=dp.grad_scale, ignore_index=ignore_index, bucket_event=ev)
-            dp.sync_grads(dm.grads, dm.grad_split, ev)
+            weight = dp.grad_scale if weight is None else weight
+            if xb.shape[0] > 0:
+                dm.train_fwd_bwd(self._features_of(xb, is_audio), yb, cw, dropout_seed=seed, grad_scale=weight, ignore_index=ignore_index,
+                                 bucket_event=ev)
+                stats = dm.stats
+            else:
+                dm.grads.zero_()
+                ev.record()
+                stats = torch.zeros_like(dm.stats)
+            dp.sync_grads(dm.grads, dm.grad_split, ev, state=dm.state if self.spec.state_count > 0 else None, state_weight=weight)
         else:
-            dm.train_fwd_bwd(feat, yb, cw, dropout_seed=seed, ignore_index=ignore_index)
+            dm.train_fwd_bwd(self._features_of(xb, is_audio), yb, cw, dropout_seed=seed, ignore_index=ignore_index)
+            stats = dm.stats
         self._apply_optimizer(dm)
-        return dm.stats
+        return stats
 
     def train_on_batch(self, x, y):
         dm = self._device()
@@ -239,12 +251,13 @@ class KWSModel(object):
             initial_epoch=0, validation_freq=1, **kwargs):
         """Keras-style training loop (train.py:81-92).  The dataset is placed in HBM once; every epoch draws a fresh
         permutation on the device, the partial last batch is kept, per-epoch loss/accuracy are the sample-weighted
-        means of the batches.  Under torch.distributed each rank trains on its slice of every global batch."""
+        means of the batches.  Under torch.distributed each rank trains on its slice of every global batch and the
+        gradients / BatchNormalization statistics are exchanged through the C ABI (kws_amd.parallel, csrc/kws_comm.hip)."""
         import torch
         from kws_amd.parallel import DataParallel
         dm = self._device()
         cw, ig = self._loss_args()
-        dp = DataParallel()
+        dp = kwargs.pop("data_parallel", None) or DataParallel.for_device()    # injectable for tests (a forced one-rank world)
         if dp.active:
             dp.broadcast_(dm.params)
             dp.broadcast_(dm.state)
@@ -276,20 +289,18 @@ class KWSModel(object):
             seen = 0
             for i in range(steps):
                 idx = perm[i * batch_size:(i + 1) * batch_size]
+                weight = None
                 if dp.active:
-                    lo, hi = dp.shard(idx.numel())
+                    lo, hi, weight = dp.shard_plan(idx.numel())     # an empty shard (weight 0) still joins the collectives
                     idx = idx[lo:hi]
-                    if idx.numel() == 0:           # keep the collective count equal on every rank
-                        idx = perm[:1]
                 self._global_step += 1
                 seed = (self._dropout_base << 20) + self._global_step * 64 + dp.rank
-                st = self._train_batch(dm, dp, xd.index_select(0, idx), yd.index_select(0, idx), is_audio, cw, ig, seed)
+                st = self._train_batch(dm, dp, xd.index_select(0, idx), yd.index_select(0, idx), is_audio, cw, ig, seed, weight)
                 acc += st.double()
                 seen += idx.numel()
             tot = torch.cat([acc, torch.tensor([float(seen)], dtype=torch.float64, device=xd.device)])
             if dp.active:
-                dp.sum_(tot)
-                dp.mean_(dm.state)               # BatchNormalization moving statistics: average the replicas
+                dp.sum_(tot)                     # (the BatchNormalization moving statistics are averaged every step)
             tot = tot.cpu().numpy()
             logs = {'loss': float(tot[0] / tot[2]), 'accuracy': float(tot[1] / tot[2])}
             if validation_data is not None and (epoch + 1) % validation_freq == 0:

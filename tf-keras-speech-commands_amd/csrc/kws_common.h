@@ -43,10 +43,9 @@ inline int fail(int code, const char *fmt, ...)
 // instead of being masked after the load, so a fragment load has no consumer until its MFMA (the prefetch can overlap).
 const float *zero_page();
 
-// Library-internal side stream and a small pool of timing-disabled events of the current device (created once): the
-// backward pass forks wgrad onto the side stream while dgrad / BN-backward continue on the caller's stream.
-hipStream_t side_stream();
-hipEvent_t sync_event(int idx);   // idx < 16
+// library-wide defaults of the per-model precision attributes (kws_model_set_precision)
+int default_matrix_precision();
+int default_infer_precision();
 
 // Opt-in per-launch timing (kws_prof_enable / kws_prof_report): HIP events recorded on the launch stream around each
 // kernel.  Disabled (the default) it costs one relaxed load per launch site.

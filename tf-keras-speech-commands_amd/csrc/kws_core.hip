@@ -44,34 +44,6 @@ const float *zero_page()
     return static_cast<const float *>(pages[dev]);
 }
 
-namespace {
-struct DevRes { hipStream_t side = nullptr; hipEvent_t ev[16] = {nullptr}; };
-DevRes *dev_res()
-{
-    static std::mutex mu;
-    static DevRes res[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    DevRes &r = res[dev];
-    if (!r.side) {
-        {
-            // lowest priority: the side stream carries the weight-gradient kernels, which must not delay the small kernels of
-            // the caller's (critical-path) stream when both have work queued
-            int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
-            if (hipStreamCreateWithPriority(&r.side, hipStreamNonBlocking, least) != hipSuccess) return nullptr;
-        }
-        for (auto &e : r.ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    }
-    return &r;
-}
-}  // namespace
-
-hipStream_t side_stream() { DevRes *r = dev_res(); return r ? r->side : nullptr; }
-hipEvent_t sync_event(int idx) { DevRes *r = dev_res(); return (r && idx >= 0 && idx < 16) ? r->ev[idx] : nullptr; }
-
 bool prof_on() { return g_prof_on.load(std::memory_order_relaxed); }
 
 const char *prof_name(const char *base, int layer)

@@ -495,6 +495,23 @@ __global__ __launch_bounds__(kGenWaves * 64) void featurize_generic_kernel(const
 // ---------------------------------------------------------------------------------------------
 // host side: parameter geometry and table construction (double precision, then rounded once)
 // ---------------------------------------------------------------------------------------------
+constexpr size_t kMaxLdsBytes = 160 * 1024;      // LDS per workgroup on gfx950
+
+// wave jobs of the n_fft = 1024 kernel: fpw consecutive frames of one clip.  Long clips: an equal share per wave of a block;
+// short ones (a streaming step has 2 frames per stream): a whole tail batch per job so that one wave serves a stream
+static void feat_job_shape(FeatDev &d)
+{
+    d.fpw = (d.n_frames + kWaves - 1) / kWaves;
+    if (!d.use_delta) d.fpw = std::max(d.fpw, std::min(d.n_frames, d.tail_batch));
+    d.fpw = std::max(1, d.fpw);
+    d.jpc = std::max(1, (d.n_frames + d.fpw - 1) / d.fpw);
+}
+
+static size_t generic_smem_bytes(const FeatDev &d)
+{
+    return (size_t)kGenWaves * d.n_fft * 8 + kGenWaves * 256 + 4 * (size_t)round4(d.n_frames * d.n_out);
+}
+
 static size_t feat_smem_bytes(const FeatDev &d)
 {
     return (size_t)kWaves * (kFftTile * 8 + 4 * (d.tail_batch * 64 + 64 + 4)) +
@@ -777,11 +794,18 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     d.bfirst = reinterpret_cast<const int *>(base + o_bf);
     d.bwidth = reinterpret_cast<const int *>(base + o_bwd);
     d.bw = reinterpret_cast<const float *>(base + o_bw);
-    f->smem_bytes = feat_smem_bytes(d);
-    if (f->smem_bytes > 64 * 1024) {
+    // the LDS the launch will ask for (same job shape as launch_featurize / launch_generic, same 160 KiB limit)
+    if (d.n_fft == 1024) {
+        feat_job_shape(d);
+        f->smem_bytes = feat_smem_bytes(d);
+    } else {
+        f->smem_bytes = generic_smem_bytes(d);
+    }
+    if (f->smem_bytes > kMaxLdsBytes) {
+        const size_t need = f->smem_bytes;
         (void)hipFree(f->dmem);
         delete f;
-        return fail(KWS_ERR_UNSUPPORTED, "featurizer needs %zu B of LDS (> 160 KiB)", f->smem_bytes);
+        return fail(KWS_ERR_UNSUPPORTED, "featurizer needs %zu B of LDS per block (> %d KiB)", need, (int)(kMaxLdsBytes / 1024));
     }
     *out = f;
     return KWS_OK;
@@ -812,8 +836,8 @@ int kws_featurizer_bank(const kws_featurizer *f, float *host_bank, size_t count)
 static int launch_generic(const FeatDev &d, const void *wav, int wav_dtype, int B, int64_t stride, const int32_t *valid_len,
                           float *feat, void *stream)
 {
-    const size_t smem = (size_t)kGenWaves * d.n_fft * 8 + kGenWaves * 256 + 4 * (size_t)round4(d.n_frames * d.n_out);
-    if (smem > 160 * 1024) return fail(KWS_ERR_UNSUPPORTED, "n_fft=%d with %d frames needs %zu B of LDS (> 160 KiB)", d.n_fft, d.n_frames, smem);
+    const size_t smem = generic_smem_bytes(d);
+    if (smem > kMaxLdsBytes) return fail(KWS_ERR_UNSUPPORTED, "n_fft=%d with %d frames needs %zu B of LDS (> 160 KiB)", d.n_fft, d.n_frames, smem);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)B), block(kGenWaves * 64);
     if (wav_dtype == KWS_WAV_F32) {
@@ -840,14 +864,9 @@ static int launch_featurize(const FeatDev &d0, const void *wav, int wav_dtype, i
 {
     if (d0.n_fft != 1024) return launch_generic(d0, wav, wav_dtype, B, stride, valid_len, feat, stream);
     FeatDev d = d0;
-    // wave jobs: fpw consecutive frames of one clip.  Long clips: an equal share per wave of a block; short ones (a
-    // streaming step has 2 frames per stream): a whole tail batch per job so that one wave serves a stream
-    d.fpw = (d.n_frames + kWaves - 1) / kWaves;
-    if (!d.use_delta) d.fpw = std::max(d.fpw, std::min(d.n_frames, d.tail_batch));
-    d.fpw = std::max(1, d.fpw);
-    d.jpc = std::max(1, (d.n_frames + d.fpw - 1) / d.fpw);
+    feat_job_shape(d);
     const size_t smem = feat_smem_bytes(d);
-    if (smem > 160 * 1024) return fail(KWS_ERR_UNSUPPORTED, "%d frames need %zu B of LDS (> 160 KiB)", d.n_frames, smem);
+    if (smem > kMaxLdsBytes) return fail(KWS_ERR_UNSUPPORTED, "%d frames need %zu B of LDS (> 160 KiB)", d.n_frames, smem);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long jobs = (long)B * d.jpc;
     const dim3 grid((unsigned)(d.use_delta ? B : (jobs + kWaves - 1) / kWaves)), block(kThreads);
@@ -884,8 +903,7 @@ int kws_featurizer_occupancy(const kws_featurizer *f, int *blocks_per_cu, size_t
 {
     if (!f || !blocks_per_cu) return fail(KWS_ERR_INVALID, "null argument");
     const bool tuned = f->dev.n_fft == 1024;
-    const size_t smem = tuned ? feat_smem_bytes(f->dev)
-                              : (size_t)kGenWaves * f->dev.n_fft * 8 + kGenWaves * 256 + 4 * (size_t)round4(f->dev.n_frames * f->dev.n_out);
+    const size_t smem = f->smem_bytes;
     if (lds_bytes) *lds_bytes = smem;
     int nb = 0;
     if (tuned)

@@ -537,12 +537,31 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float *__restrict__
         const int k = i / C, c = i % C;
         float acc = 0.f;
         for (int s = 0; s < kHeadBwdRows; ++s) acc = fmaf(xs[s * K + k], ds[s * C + c], acc);
-        atomicAdd(dw2 + i, acc);
+        if (dw2) atomicAdd(dw2 + i, acc);
     }
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = 0.f;
         for (int s = 0; s < kHeadBwdRows; ++s) acc += ds[s * C + c];
-        atomicAdd(db2 + c, acc);
+        if (db2) atomicAdd(db2 + c, acc);
+    }
+}
+
+// Deterministic form of the head's weight / bias gradient (kws_model_set_deterministic): one thread per entry of dW2 (and of
+// db2) walks the batch in order, so the sums do not depend on which block's float atomic lands first.  For parity tests.
+__global__ __launch_bounds__(256) void head_wgrad_det_kernel(const float *__restrict__ x, const float *__restrict__ dlogits,
+                                                              float *__restrict__ dw2, float *__restrict__ db2, int B, int K, int C)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < K * C) {
+        const int k = i / C, c = i - k * C;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc = fmaf(x[(long)b * K + k], dlogits[(long)b * C + c], acc);
+        dw2[i] += acc;
+    } else if (i < K * C + C) {
+        const int c = i - K * C;
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += dlogits[(long)b * C + c];
+        db2[c] += acc;
     }
 }
 
@@ -634,8 +653,9 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restr
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < K * C; i += 256) atomicAdd(dw2 + i, ws[i]);
-    if ((int)threadIdx.x < C) atomicAdd(db2 + threadIdx.x, accb);
+    if (dw2)
+        for (int i = threadIdx.x; i < K * C; i += 256) atomicAdd(dw2 + i, ws[i]);
+    if (db2 && (int)threadIdx.x < C) atomicAdd(db2 + threadIdx.x, accb);
     if (stats && blockIdx.x == 0) {                 // deterministic: fixed strided partition, tree in double
         double sl = 0.0, sc = 0.0;
         for (int i = threadIdx.x; i < B; i += 256) { sl += (double)loss_i[i]; sc += (double)correct_i[i]; }

@@ -27,6 +27,16 @@ inline int same_pad_before(int n, int k, int s)
     return total / 2;   // TF 'SAME': the extra element goes to the end
 }
 
+#define KWS_TRY_NB(...)               \
+    do {                              \
+        const int rc__ = (__VA_ARGS__); \
+        if (rc__ < 0) return rc__;    \
+    } while (0)
+#define KWS_TRY(...)                  \
+    do {                              \
+        if (int rc__ = (__VA_ARGS__)) return rc__; \
+    } while (0)
+
 constexpr int kCh[5] = {1, 16, 32, 64, 128};
 constexpr int kMaxStatBlocks = kStatStride;
 
@@ -107,12 +117,13 @@ inline void stat_grid(long M, int C, int &nblk, int &rows)
 }
 
 template <int CR, int CO, int MODE, int EPI>
-void launch_gemm(const float *src, const float *w, const float *bias, float *dst, const ConvGeom &g, hipStream_t s)
+int launch_gemm(const float *src, const float *w, const float *bias, float *dst, const ConvGeom &g, hipStream_t s)
 {
     const long M = (long)g.B * g.Ho * g.Wo;
     static const std::string name = std::string("conv_gemm_fwd<") + std::to_string(CR) + "," +
                                     std::to_string(CO) + ">";
     KWS_LAUNCH(name.c_str(), (conv_gemm_kernel<CR, CO, MODE, EPI>), dim3(blocks_for(M, 64)), dim3(256), 0, s, src, w, bias, dst, g);
+    return KWS_OK;
 }
 
 // CUs of the current device (cached) and resident blocks per CU of a kernel at a given dynamic LDS size
@@ -138,31 +149,38 @@ static int resident_blocks(K kernel, int threads, size_t smem)
 // dW += wgrad(x, dz).  The grid is sized so that all blocks are resident at once (ONE round): with more blocks than slots the
 // last round runs on a fraction of the chip (measured on conv4: 990 blocks on 768 slots left the CUs idle 43 % of the time).
 template <int CIN, int COUT, int GPB>
-void launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s)
+int launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s, bool deterministic = false)
 {
+    const float *zp = zero_page();
+    if (!zp) return fail(KWS_ERR_NOMEM, "cannot allocate the zero page on this device");
     constexpr int CB = CIN >= 64 ? 64 : CIN;
     constexpr size_t smem = (4 * 64 * 4 + 16 * COUT) * sizeof(float);
     const long M = (long)g.B * g.Ho * g.Wo;
     const int ngroups = g.KH * g.KW * (CIN / CB), gy = (ngroups + GPB - 1) / GPB;
     const long steps = (M + 3) / 4;                                   // 4-pixel MFMA k-steps
     static const int occ = resident_blocks(conv_wgrad_direct_kernel<CIN, COUT, GPB>, 256, smem);
-    const long slots = std::max<long>(1, (long)cu_count() * occ / gy); // blocks along x that fit at once
+    // deterministic: ONE block along the pixel axis, so every output element receives a single add onto the cleared buffer
+    const long slots = deterministic ? 1 : std::max<long>(1, (long)cu_count() * occ / gy); // blocks along x that fit at once
     // >= 8 steps per wave so the end-of-block tile reduction amortises
     const long gx_want = std::max<long>(1, std::min<long>(slots, (steps + 4 * 8 - 1) / (4 * 8)));
     const int spw = (int)((steps + 4 * gx_want - 1) / (4 * gx_want));
     const long gx = (steps + 4L * spw - 1) / (4L * spw);
     static const std::string name = "conv_wgrad<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
     KWS_LAUNCH(name.c_str(), (conv_wgrad_direct_kernel<CIN, COUT, GPB>), dim3((unsigned)gx, (unsigned)gy), dim3(256), smem,
-               s, x, dz, dw, zero_page(), g, spw);
+               s, x, dz, dw, zp, g, spw);
+    return KWS_OK;
 }
 
 // dW += wgrad(x, dz) in the split-precision form (conv_wgrad_bf16_kernel): grid = (tap groups) * (pixel ranges), one resident
 // round, the taps of a range on one XCD.  TPB = taps per block: 3 (one kernel row, dz split once for three products) pays
 // for conv3 (0.047 -> 0.042 ms); for conv4 its 238 registers and 74 KB of LDS cost more than they save (0.111 -> 0.122 ms).
 template <int CIN, int COUT, int TPB, bool DPRE = false>
-void launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s, __bf16 *const *dz_planes = nullptr)
+int launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s, __bf16 *const *dz_planes = nullptr,
+                      bool deterministic = false)
 {
-    if (TPB != 1 && g.KW != TPB) { fail(KWS_ERR_UNSUPPORTED, "split-precision weight gradient expects a kernel %d taps wide", TPB); return; }
+    if (TPB != 1 && g.KW != TPB) return fail(KWS_ERR_UNSUPPORTED, "split-precision weight gradient expects a kernel %d taps wide", TPB);
+    const float *zp = zero_page();
+    if (!zp) return fail(KWS_ERR_NOMEM, "cannot allocate the zero page on this device");
     constexpr size_t stage = (size_t)3 * 32 * 4 * (TPB * tr_row_words(CIN) + tr_row_words(COUT)), tile = (size_t)CIN * COUT * sizeof(float);
     constexpr size_t smem = stage > tile ? stage : tile;
     static const int occ = [] {
@@ -174,29 +192,35 @@ void launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeo
     // ranges: a multiple of 8 (one per XCD), at most one resident round, at least 4 chunks per block
     long nranges = std::max<long>(8, ((long)cu_count() * occ / ngroups) / 8 * 8);
     nranges = std::min<long>(nranges, std::max<long>(8, (nchunk / 4 + 7) / 8 * 8));
-    const int cpb = (int)((nchunk + nranges - 1) / nranges);
+    int cpb = (int)((nchunk + nranges - 1) / nranges);
+    if (deterministic) { nranges = 8; cpb = (int)nchunk; }   // range 0 takes every chunk: a single add per output element
     static const std::string name = "conv_wgrad_bf16<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
     const Bf16Planes dpl{{DPRE ? dz_planes[0] : nullptr, DPRE ? dz_planes[1] : nullptr, DPRE ? dz_planes[2] : nullptr}};
     KWS_LAUNCH(name.c_str(), (conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE>), dim3((unsigned)(nranges * ngroups)), dim3(256), smem, s, x, dz, dw,
-               zero_page(), g, cpb, (int)nranges, dpl);
+               zp, g, cpb, (int)nranges, dpl);
+    return KWS_OK;
 }
 
 // dx <- dgrad(dz): ONE launch over every stride-parity class of the input pixels (blockIdx.y = class).  MW (16-row tiles
 // per wave) is picked so that the waves divide evenly over the SIMDs: every SIMD's matrix pipe then runs
 // ceil(waves / SIMDs) * MW tile-times, and the smallest such product wins (ties: the larger MW reuses weights more).
 template <int CR, int CO, int MW, int STRIDE>
-void launch_dgrad_mw(const float *dz, const float *w, float *dx, const ConvGeom &g, const DgradClasses &cls, int ncls, long max_rows,
+int launch_dgrad_mw(const float *dz, const float *w, float *dx, const ConvGeom &g, const DgradClasses &cls, int ncls, long max_rows,
                      hipStream_t s)
 {
     static const std::string name = "conv_dgrad<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
+    const float *zp = zero_page();
+    if (!zp) return fail(KWS_ERR_NOMEM, "cannot allocate the zero page on this device");
     KWS_LAUNCH(name.c_str(), (conv_dgrad_direct_kernel<CR, CO, MW, STRIDE>), dim3(blocks_for(max_rows, 64 * MW), (unsigned)ncls), dim3(256), 0, s,
-               dz, w, dx, zero_page(), g, cls);
+               dz, w, dx, zp, g, cls);
+    return KWS_OK;
 }
 
 template <int CR, int CO, int STRIDE>
-void launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g, hipStream_t s)
+int launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g, hipStream_t s)
 {
-    if (g.KH > 8 * g.stride || g.KW > 8 * g.stride) { fail(KWS_ERR_UNSUPPORTED, "kernel %dx%d too large for the dgrad tap masks", g.KH, g.KW); return; }
+    if (g.KH > 8 * g.stride || g.KW > 8 * g.stride)
+        return fail(KWS_ERR_UNSUPPORTED, "kernel %dx%d too large for the dgrad tap masks (at most %d taps per axis)", g.KH, g.KW, 8 * g.stride);
     DgradClasses cls;
     int ncls = 0;
     long rows[4] = {0, 0, 0, 0}, max_rows = 0;
@@ -209,7 +233,7 @@ void launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g,
             cls.c[ncls++] = c;
         }
     for (int i = ncls; i < 4; ++i) cls.c[i] = DgradClass{0, 0, 0, 0};
-    if (g.stride > 2) { fail(KWS_ERR_UNSUPPORTED, "dgrad is built for strides 1 and 2"); return; }
+    if (g.stride > 2) return fail(KWS_ERR_UNSUPPORTED, "dgrad is built for strides 1 and 2");
     const long simds = 4L * cu_count();
     int best = 4;
     long best_cost = -1;
@@ -220,16 +244,17 @@ void launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g,
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mw; }
     }
     switch (best) {
-    case 1: launch_dgrad_mw<CR, CO, 1, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s); break;
-    case 2: launch_dgrad_mw<CR, CO, 2, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s); break;
-    case 3: launch_dgrad_mw<CR, CO, 3, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s); break;
-    default: launch_dgrad_mw<CR, CO, 4, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s); break;
+    case 1: return launch_dgrad_mw<CR, CO, 1, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s);
+    case 2: return launch_dgrad_mw<CR, CO, 2, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s);
+    case 3: return launch_dgrad_mw<CR, CO, 3, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s);
+    default: return launch_dgrad_mw<CR, CO, 4, STRIDE>(dz, w, dx, g, cls, ncls, max_rows, s);
     }
 }
 
 // 1 (default): conv3, conv4 and the dense layer run as split-precision bf16 products (kws_device.h: mfma_bf16x6, three-way
 // split, fp32-level error); 0: every product on the fp32 MFMA.  kws_set_matrix_precision() switches it library-wide.
 static int g_matrix_precision = 1;
+static inline int matrix_prec(const kws_model *m) { return m->matrix_precision >= 0 ? m->matrix_precision : g_matrix_precision; }
 
 // returns the number of blocks that wrote BatchNorm partial sums (0: `partial` was not given or the grid exceeds its stride)
 template <int CR, int CO, int MODE, int EPI>
@@ -325,7 +350,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool pool[4] = {true, true, false, true};
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
 
-    const bool bf16 = g_matrix_precision == 1;
+    const bool bf16 = matrix_prec(m) == 1;
+    ModelRes *R = nullptr;       // only the split-on-the-side-stream branch below needs the model's stream / events
     // training in split precision at a geometry the MFMA layer-1 kernels cover: the weight split and the gradient clear ride
     // in the grid of the layer-1 statistics kernel (l1m_stats_prep_kernel) -- no side-stream branch, no events
     const bool prep_in_stats = bf16 && training && d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * kL1Stage &&
@@ -334,16 +360,17 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         if (zero_grads && zeroed) *zeroed = true;
     } else if (bf16 && training) {
         // the h/m/l planes are first needed by conv3: split on the side stream beside layers 1-2, join before conv3
-        hipStream_t s2 = side_stream();
-        if (!s2) return fail(KWS_ERR_HIP, "cannot create the internal side stream");
-        KWS_HIP_CHECK(hipEventRecord(sync_event(10), s));
-        KWS_HIP_CHECK(hipStreamWaitEvent(s2, sync_event(10), 0));
+        R = const_cast<kws_model *>(m)->dev_res();
+        if (!R) return fail(KWS_ERR_HIP, "cannot create the model's side stream / events on this device");
+        hipStream_t s2 = R->side;
+        KWS_HIP_CHECK(hipEventRecord(R->ev[10], s));
+        KWS_HIP_CHECK(hipStreamWaitEvent(s2, R->ev[10], 0));
         if (zero_grads) {
             KWS_HIP_CHECK(hipMemsetAsync(zero_grads, 0, sizeof(float) * (size_t)m->P, s2));
             if (zeroed) *zeroed = true;
         }
         if (int rc = split_weights(m, params, w, s2)) return rc;
-        KWS_HIP_CHECK(hipEventRecord(sync_event(11), s2));
+        KWS_HIP_CHECK(hipEventRecord(R->ev[11], s2));
     } else if (bf16) {
         // inference stays on ONE stream: callers capture it into hipGraphs, and a fork to the library's side stream inside
         // several captured graphs made every graph after the first replay 0.2 ms slower
@@ -411,19 +438,23 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         } else if (l == 2 && bf16 && !training) {
             // inference: BatchNorm affine + ReLU6 in the epilogue, a3 written directly (conv3 has no pool)
             const BnCoef k3 = coef_of(w.coef[2], 64);
-            launch_bf16<32, 64, MODE_FWD, EPI_BN_RELU6>("conv_bf16_fwd_bn", in, w.wsp[0], k3.scale, w.a[2], geom3x3(B, Hs[2], Ws[2], 2), s, nullptr, k3.shift);
+            KWS_TRY_NB(launch_bf16<32, 64, MODE_FWD, EPI_BN_RELU6>("conv_bf16_fwd_bn", in, w.wsp[0], k3.scale, w.a[2], geom3x3(B, Hs[2], Ws[2], 2), s, nullptr, k3.shift));
             continue;
         } else if (l == 2) {
-            if (bf16 && training && !prep_in_stats) KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(11), 0));     // the weight planes are ready
+            if (bf16 && training && !prep_in_stats) KWS_HIP_CHECK(hipStreamWaitEvent(s, R->ev[11], 0));     // the weight planes are ready
             // the split-precision kernels write the BatchNorm partial sums from their epilogue when training
-            if (bf16) fused_stat_blocks = launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s,
-                                                                                training ? w.partial : nullptr);
-            else launch_gemm<32, 64, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s);
+            if (bf16) {
+                fused_stat_blocks = launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s,
+                                                                          training ? w.partial : nullptr);
+                if (fused_stat_blocks < 0) return fused_stat_blocks;
+            } else KWS_TRY(launch_gemm<32, 64, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s));
         } else {
             // activation='relu', cnn.py:55
-            if (bf16) fused_stat_blocks = launch_bf16<64, 128, MODE_FWD, EPI_RELU>("conv_bf16_fwd", in, w.wsp[1], nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s,
-                                                                                 training ? w.partial : nullptr);
-            else launch_gemm<64, 128, MODE_FWD, EPI_RELU>(in, kern, nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s);
+            if (bf16) {
+                fused_stat_blocks = launch_bf16<64, 128, MODE_FWD, EPI_RELU>("conv_bf16_fwd", in, w.wsp[1], nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s,
+                                                                           training ? w.partial : nullptr);
+                if (fused_stat_blocks < 0) return fused_stat_blocks;
+            } else KWS_TRY(launch_gemm<64, 128, MODE_FWD, EPI_RELU>(in, kern, nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s));
         }
         BnCoef k = coef_of(w.coef[l], C);
         if (training) {
@@ -452,8 +483,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     // Dense(128, use_bias=True) + ReLU6 as a (H4 x W4) 'valid' convolution over the pooled map (Flatten is h,w,c)
     ConvGeom g;
     g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
-    if (bf16) launch_bf16<128, 128, MODE_FWD, EPI_BIAS_RELU6>("conv_bf16_fwd", w.a[3], w.wsp[2], params + m->o_db, w.d1, g, s);
-    else launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s);
+    if (bf16) KWS_TRY_NB(launch_bf16<128, 128, MODE_FWD, EPI_BIAS_RELU6>("conv_bf16_fwd", w.a[3], w.wsp[2], params + m->o_db, w.d1, g, s));
+    else KWS_TRY(launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s));
     KWS_LAUNCH_CHECK("simple_cnn forward");
     return KWS_OK;
 }
@@ -472,20 +503,22 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     // The weight-gradient GEMM of a layer only READS (x, dz) and adds into grads; the data-gradient GEMM and the next
     // layer's BN backward do not depend on it.  Each of them alone leaves the MFMA pipe more than half idle, so wgrad runs
     // on the library's side stream (fork after dz is final, one join at the end) and shares the chip with the main chain.
-    hipStream_t s2 = side_stream();
-    if (!s2) return fail(KWS_ERR_HIP, "cannot create the internal side stream");
+    ModelRes *R = const_cast<kws_model *>(m)->dev_res();
+    if (!R) return fail(KWS_ERR_HIP, "cannot create the model's side stream / events on this device");
+    hipStream_t s2 = R->side;
+    const int mprec = matrix_prec(m);
+    const bool det = m->deterministic != 0;
     auto fork = [&](int ev) -> int {          // side stream waits for everything enqueued on s so far
-        KWS_HIP_CHECK(hipEventRecord(sync_event(ev), s));
-        KWS_HIP_CHECK(hipStreamWaitEvent(s2, sync_event(ev), 0));
+        KWS_HIP_CHECK(hipEventRecord(R->ev[ev], s));
+        KWS_HIP_CHECK(hipStreamWaitEvent(s2, R->ev[ev], 0));
         return KWS_OK;
     };
     // head: dW2, db2, dd1 (gated by dense's ReLU6)
     {
         // the MFMA head kernel also leaves the dense bias gradient (column sums of dd1) and the loss / accuracy sums
         const bool fuse = head_bwd_fuses(m);
-        const int rc = run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s, fuse ? grads + m->o_db : nullptr, w.loss_i, w.correct_i,
-                                    fuse ? stats : nullptr);
-        if (rc) return rc;
+        KWS_TRY(run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s, fuse && !det ? grads + m->o_db : nullptr, w.loss_i, w.correct_i,
+                             fuse ? stats : nullptr, det));
     }
     // dense 256->128: bias grad (column sums), wgrad, dgrad -> da4 (gradient w.r.t. the dropped, flattened map)
     {
@@ -494,15 +527,15 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         // its own fork, although every event costs the main chain 6-8 us: started later, together with conv4's weight
         // gradient, the step was 2 % slower (same-box A/B)
         if (int rc = fork(0)) return rc;
-        launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s2);
+        KWS_TRY(launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s2, det));
         int nblk, rows;
         stat_grid(B, 128, nblk, rows);
-        if (!head_bwd_fuses(m)) {
+        if (!head_bwd_fuses(m) || det) {
             KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
             KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
         }
-        if (g_matrix_precision == 1) launch_bf16<128, 128, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.dd1, w.wsp[2], nullptr, w.da4, g, s);
-        else launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
+        if (mprec == 1) KWS_TRY_NB(launch_bf16<128, 128, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.dd1, w.wsp[2], nullptr, w.da4, g, s));
+        else KWS_TRY(launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s));
     }
     for (int l = 3; l >= 1; --l) {
         const int C = kCh[l + 1];
@@ -516,7 +549,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         // conv2 (split precision): g stays compact -- the routed value per pool window in place of da[1], the element index as
         // a byte in the (dead by now) da[2] buffer -- and the clip data gradient rebuilds it while staging: 54 MB less to
         // write here and 54 MB less to read there at B = 4096
-        const bool compact_g = l == 1 && g_matrix_precision == 1 && Hz[1] * Wz[1] * 8 <= 1280 &&
+        const bool compact_g = l == 1 && mprec == 1 && Hz[1] * Wz[1] * 8 <= 1280 &&
                                (size_t)(Hz[1] / 2) * (Wz[1] / 2) * 32 <= sizeof(float) * (size_t)d.H3 * d.W3 * 64;
         if (pool[l]) {
             const long NW = (long)B * (Hz[l] / 2) * (Wz[l] / 2);       // one thread per (pool window, channel)
@@ -534,7 +567,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                    grads + m->o_g[l], grads + m->o_b[l], k);
         if (l == 1)
             ;                                                   // fused into conv_dgrad_clip's staging below
-        else if (l == 3 && g_matrix_precision == 1)
+        else if (l == 3 && mprec == 1)
             // split precision: dz4 leaves as bf16 h/m/l planes, which is what both of its consumers stage (no fp32 dz4)
             KWS_LAUNCH(prof_name("bn_bwd_apply_planes_kernel", l + 1), bn_bwd_apply_planes_kernel<true>, dim3(blocks_for(M * C / 4, 256)), dim3(256), 0, s,
                        w.z[l], w.gz[l], k, params + m->o_g[l], M * C / 4, C, (Bf16PlanesOut{{w.dzp[0], w.dzp[1], w.dzp[2]}}));
@@ -551,8 +584,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
-            if (g_matrix_precision == 1) launch_wgrad_bf16<64, 128, 1, true>(in, nullptr, dk, g, s2, w.dzp);
-            else launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2);
+            if (mprec == 1) KWS_TRY(launch_wgrad_bf16<64, 128, 1, true>(in, nullptr, dk, g, s2, w.dzp, det));
+            else KWS_TRY(launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2, det));
             if (bucket_event) {
                 // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here: it
                 // runs the dense and conv4 weight gradients in order and joined the caller's stream at fork(3), i.e. after
@@ -560,13 +593,13 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                 // not wait for the conv4 wgrad.
                 KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
             }
-            if (g_matrix_precision == 1) launch_bf16<128, 64, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", nullptr, w.wsp[1], nullptr, w.da[2], g, s, nullptr, nullptr, w.dzp);
-            else launch_dgrad<128, 64, 1>(w.gz[3], kern, w.da[2], g, s);
+            if (mprec == 1) KWS_TRY_NB(launch_bf16<128, 64, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", nullptr, w.wsp[1], nullptr, w.da[2], g, s, nullptr, nullptr, w.dzp));
+            else KWS_TRY(launch_dgrad<128, 64, 1>(w.gz[3], kern, w.da[2], g, s));
         } else if (l == 2) {
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
-            if (g_matrix_precision == 1) launch_wgrad_bf16<32, 64, 3>(in, w.gz[2], dk, g, s2);
-            else launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2);
-            launch_dgrad<64, 32, 2>(w.gz[2], kern, w.da[1], g, s);
+            if (mprec == 1) KWS_TRY(launch_wgrad_bf16<32, 64, 3>(in, w.gz[2], dk, g, s2, nullptr, det));
+            else KWS_TRY(launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2, det));
+            KWS_TRY(launch_dgrad<64, 32, 2>(w.gz[2], kern, w.da[1], g, s));
         } else {
             // conv2 (16 -> 32, 3x3, stride 1): clip-resident kernels, the clip's tiles are staged in LDS once
             const int H1 = Hs[1], W1 = Ws[1];
@@ -579,7 +612,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const size_t smd = sizeof(float) * (size_t)(H1 + 2) * (W1 + 2) * (32 + 4);
             BnBwdArgs bn = {w.z[1], params + m->o_g[1], k.mean, k.inv, k.k2, k.k3};
             if (compact_g) { bn.gw = w.da[1]; bn.arg = reinterpret_cast<const unsigned char *>(w.da[2]); }
-            if (g_matrix_precision == 1) {
+            if (mprec == 1) {
                 // split-precision form: 2 blocks per CU by registers (the weight fragments of all nine taps stay in them)
                 const size_t smdb = (size_t)12 * 16 * (((H1 + 2) * (W1 + 2) + 15) & ~15);
                 if (compact_g)
@@ -591,15 +624,16 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             } else
                 KWS_LAUNCH("conv_dgrad_clip<32,16>", (conv_dgrad_clip_kernel<32, true>), dim3(nblk_d), dim3(256), smd, s, w.gz[1], kern, w.da[0], B, H1, W1, bn);
             if (int rc = fork(1)) return rc;
-            if (g_matrix_precision == 1 && H1 * W1 <= 160) {
+            if (mprec == 1 && H1 * W1 <= 160) {
                 const size_t smwb = std::max((size_t)3 * 32 * (H1 + 2) * (W1 + 2) + (size_t)6 * 32 * (H1 * W1 + 1), sizeof(float) * 9 * 16 * 32);
                 // two blocks per CU although three fit: the third takes the LDS the layer-1 kernels of the main chain need beside it
                 // (same-box A/B: 0.785 ms/step with one or two, 0.800 with three)
                 static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel, 256, smwb);
-                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel, dim3(even_grid(cu_count() * std::min(occ, 2))), dim3(256), smwb, s2, in,
+                // deterministic: one persistent block walks every clip, so dW2 is a single add onto the cleared buffer
+                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel, dim3(det ? 1u : even_grid(cu_count() * std::min(occ, 2))), dim3(256), smwb, s2, in,
                            w.gz[1], dk, B, H1, W1);
             } else
-                KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);
+                KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(det ? 1u : nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);
         }
     }
     // layer 1: da1 -> (dgamma1, dbeta1, dW1) with conv1 recomputed; no z1-sized tensor is read or written
@@ -619,19 +653,19 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                        cpw, w.partial);
             KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(64), 0, s, w.partial, nbm, M1, 16,
                        params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], k1);
-            KWS_LAUNCH("l1m_bwd_wgrad_kernel", l1m_bwd_wgrad_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
-                       grads + m->o_k[0], B, d.H0, d.W0, cpw);
+            KWS_LAUNCH("l1m_bwd_wgrad_kernel", l1m_bwd_wgrad_kernel, dim3(det ? 1 : nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
+                       grads + m->o_k[0], B, d.H0, d.W0, det ? (B + 3) / 4 : cpw);
         } else {
             KWS_LAUNCH("l1_bwd_reduce_kernel", l1_bwd_reduce_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
                        cpb, w.partial);
             KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(64), 0, s, w.partial, nb, M1, 16,
                        params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], k1);
-            KWS_LAUNCH("l1_bwd_wgrad_kernel", l1_bwd_wgrad_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
-                       grads + m->o_k[0], B, d.H0, d.W0, cpb);
+            KWS_LAUNCH("l1_bwd_wgrad_kernel", l1_bwd_wgrad_kernel<16>, dim3(det ? 1 : nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
+                       grads + m->o_k[0], B, d.H0, d.W0, det ? B : cpb);
         }
     }
-    KWS_HIP_CHECK(hipEventRecord(sync_event(9), s2));             // join: every wgrad is part of the caller's stream order again
-    KWS_HIP_CHECK(hipStreamWaitEvent(s, sync_event(9), 0));
+    KWS_HIP_CHECK(hipEventRecord(R->ev[9], s2));             // join: every wgrad is part of the caller's stream order again
+    KWS_HIP_CHECK(hipStreamWaitEvent(s, R->ev[9], 0));
     KWS_LAUNCH_CHECK("simple_cnn backward");
     return KWS_OK;
 }
@@ -647,6 +681,7 @@ ConvGeom geom1x1(int B, int H, int W)
 
 // Storage / matrix-operand precision of simple_cnn_lite INFERENCE (kws_set_inference_precision): 0 = fp32, 1 = fp16
 static int g_infer_precision = 0;
+static inline int infer_prec(const kws_model *m) { return m->infer_precision >= 0 ? m->infer_precision : g_infer_precision; }
 
 // fp16 inference (kws_lite_f16.h): front kernel with fp16 output, then ONE kernel from a2 to the probabilities.
 // The fp16 weight blob lives at the head of the (otherwise unused in inference) double partial slab.
@@ -720,9 +755,9 @@ int lite_forward(const kws_model *m, const float *feat, int B, const float *para
         const float *pwk = params + m->o_pwk[l], *pwb = params + m->o_pwb[l];
         const ConvGeom g1 = geom1x1(B, Hz[l], Wz[l]);
         if (l == 0) KWS_LAUNCH("pw1_fwd_kernel", pw1_fwd_kernel<16>, dim3(blocks_for(M * 16, 256)), dim3(256), 0, s, w.dwo[0], pwk, pwb, w.z[0], M);
-        else if (l == 1) launch_gemm<16, 32, MODE_FWD, EPI_BIAS>(w.dwo[1], pwk, pwb, w.z[1], g1, s);
-        else if (l == 2) launch_gemm<32, 64, MODE_FWD, EPI_BIAS_RELU>(w.dwo[2], pwk, pwb, w.z[2], g1, s);      // activation='relu', cnn.py:113
-        else launch_gemm<64, 128, MODE_FWD, EPI_BIAS_RELU>(w.dwo[3], pwk, pwb, w.z[3], g1, s);                  // cnn.py:122
+        else if (l == 1) KWS_TRY(launch_gemm<16, 32, MODE_FWD, EPI_BIAS>(w.dwo[1], pwk, pwb, w.z[1], g1, s));
+        else if (l == 2) KWS_TRY(launch_gemm<32, 64, MODE_FWD, EPI_BIAS_RELU>(w.dwo[2], pwk, pwb, w.z[2], g1, s));      // activation='relu', cnn.py:113
+        else KWS_TRY(launch_gemm<64, 128, MODE_FWD, EPI_BIAS_RELU>(w.dwo[3], pwk, pwb, w.z[3], g1, s));                  // cnn.py:122
         BnCoef k = coef_of(w.coef[l], C);
         if (training) {
             int nblk, rows;
@@ -741,7 +776,7 @@ int lite_forward(const kws_model *m, const float *feat, int B, const float *para
     }
     ConvGeom g;
     g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
-    launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s);
+    KWS_TRY(launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s));
     KWS_LAUNCH_CHECK("simple_cnn_lite forward");
     return KWS_OK;
 }
@@ -755,9 +790,9 @@ int lite_backward(const kws_model *m, const float *feat, int B, const float *par
     const int strd[4] = {1, 1, 2, 1};
     const bool pool[4] = {true, true, false, true};
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
+    const bool det = m->deterministic != 0;
     KWS_HIP_CHECK(hipMemsetAsync(grads, 0, sizeof(float) * (size_t)m->P, s));
-    int rc = run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s);
-    if (rc) return rc;
+    KWS_TRY(run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s, nullptr, nullptr, nullptr, nullptr, det));
     {
         ConvGeom g;
         g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
@@ -765,8 +800,8 @@ int lite_backward(const kws_model *m, const float *feat, int B, const float *par
         stat_grid(B, 128, nblk, rows);
         KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
         KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
-        launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s);
-        launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s);
+        KWS_TRY(launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s, det));
+        KWS_TRY(launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s));
     }
     for (int l = 3; l >= 0; --l) {
         const int Cin = kCh[l], C = kCh[l + 1];
@@ -801,14 +836,14 @@ int lite_backward(const kws_model *m, const float *feat, int B, const float *par
             KWS_LAUNCH(prof_name("channel_stats_kernel.bias", l + 1), channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.gz[l], M, C, rows, w.partial);
             KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(C), dim3(256), 0, s, w.partial, nblk, C, grads + m->o_pwb[l]);
             if (l == 3) {
-                launch_wgrad<64, 128, 1>(w.dwo[3], w.gz[3], grads + m->o_pwk[3], g1, s);
-                launch_dgrad<128, 64, 1>(w.gz[3], pwk, w.ddw[3], g1, s);
+                KWS_TRY(launch_wgrad<64, 128, 1>(w.dwo[3], w.gz[3], grads + m->o_pwk[3], g1, s, det));
+                KWS_TRY(launch_dgrad<128, 64, 1>(w.gz[3], pwk, w.ddw[3], g1, s));
             } else if (l == 2) {
-                launch_wgrad<32, 64, 1>(w.dwo[2], w.gz[2], grads + m->o_pwk[2], g1, s);
-                launch_dgrad<64, 32, 1>(w.gz[2], pwk, w.ddw[2], g1, s);
+                KWS_TRY(launch_wgrad<32, 64, 1>(w.dwo[2], w.gz[2], grads + m->o_pwk[2], g1, s, det));
+                KWS_TRY(launch_dgrad<64, 32, 1>(w.gz[2], pwk, w.ddw[2], g1, s));
             } else {
-                launch_wgrad<16, 32, 1>(w.dwo[1], w.gz[1], grads + m->o_pwk[1], g1, s);
-                launch_dgrad<32, 16, 1>(w.gz[1], pwk, w.ddw[1], g1, s);
+                KWS_TRY(launch_wgrad<16, 32, 1>(w.dwo[1], w.gz[1], grads + m->o_pwk[1], g1, s, det));
+                KWS_TRY(launch_dgrad<32, 16, 1>(w.gz[1], pwk, w.ddw[1], g1, s));
             }
         }
         // depthwise 3x3
@@ -862,35 +897,106 @@ bool head_bwd_fuses(const kws_model *m) { return m->head_K % 16 == 0 && m->head_
 
 int run_head_bwd(const kws_model *m, int B, const float *params, const float *x, const float *dlogits, float *dx,
                  float *grads, bool relu6_gate, hipStream_t s, float *dx_colsum, const float *loss_i, const float *correct_i,
-                 float *stats)
+                 float *stats, bool deterministic)
 {
     const int K = m->head_K;
+    // deterministic: the kernels below only produce dx (and the loss sums); dW2 / db2 come from a batch-ordered kernel
+    float *dw2 = deterministic ? nullptr : grads + m->o_hk, *db2 = deterministic ? nullptr : grads + m->o_hb;
+    if (deterministic) {
+        dx_colsum = nullptr;
+        KWS_LAUNCH("head_wgrad_det_kernel", head_wgrad_det_kernel, dim3(blocks_for((long)K * m->C + m->C, 256)), dim3(256), 0, s, x, dlogits,
+                   grads + m->o_hk, grads + m->o_hb, B, K, m->C);
+    }
     const size_t smem = sizeof(float) * (size_t)(kHeadBwdRows * K + kHeadBwdRows * m->C);
     if (head_bwd_fuses(m)) {    // the MFMA form: W2, a 16-sample tile and dlogits padded to 48 classes live in LDS
         constexpr int G = 1;                          // 16-sample groups per block (4 measured slower: 64 blocks expose each group's staging latency)
         const size_t smem_fast = sizeof(float) * (size_t)(16 * (K + 2) + (16 + K) * 50);
         if (relu6_gate)
             KWS_LAUNCH("head_bwd_kernel", (head_bwd_mfma_kernel<true, G>), dim3(blocks_for(B, 16 * G)), dim3(256), smem_fast, s, x, params + m->o_hk, dlogits,
-                       dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C, dx_colsum, loss_i, correct_i, stats);
+                       dx, dw2, db2, B, K, m->C, dx_colsum, loss_i, correct_i, stats);
         else
             KWS_LAUNCH("head_bwd_kernel", (head_bwd_mfma_kernel<false, G>), dim3(blocks_for(B, 16 * G)), dim3(256), smem_fast, s, x, params + m->o_hk, dlogits,
-                       dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C, dx_colsum, loss_i, correct_i, stats);
+                       dx, dw2, db2, B, K, m->C, dx_colsum, loss_i, correct_i, stats);
         KWS_LAUNCH_CHECK("head backward");
         return KWS_OK;
     }
     if (relu6_gate)
         KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<true>, dim3(blocks_for(B, kHeadBwdRows)), dim3(256), smem, s, x, params + m->o_hk, dlogits,
-                   dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
+                   dx, dw2, db2, B, K, m->C);
     else
         KWS_LAUNCH("head_bwd_kernel", head_bwd_kernel<false>, dim3(blocks_for(B, kHeadBwdRows)), dim3(256), smem, s, x, params + m->o_hk, dlogits,
-                   dx, grads + m->o_hk, grads + m->o_hb, B, K, m->C);
+                   dx, dw2, db2, B, K, m->C);
     KWS_LAUNCH_CHECK("head backward");
     return KWS_OK;
 }
 
 }  // namespace kws
 
+kws::ModelRes *kws_model::dev_res()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(res_mu);
+    kws::ModelRes &r = res[dev];
+    if (!r.side) {
+        // lowest priority: the side stream carries the weight-gradient kernels, which must not delay the small kernels of
+        // the caller's (critical-path) stream when both have work queued
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+        if (hipStreamCreateWithPriority(&r.side, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); r.side = nullptr; return nullptr; }
+        for (auto &e : r.ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    return &r;
+}
+
+kws_model::~kws_model()
+{
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (auto &kv : res) {
+        if (have) (void)hipSetDevice(kv.first);
+        for (auto &e : kv.second.ev)
+            if (e) (void)hipEventDestroy(e);
+        if (kv.second.side) (void)hipStreamDestroy(kv.second.side);
+    }
+    if (have && !res.empty()) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+}
+
+namespace kws {
+int default_matrix_precision() { return g_matrix_precision; }
+int default_infer_precision() { return g_infer_precision; }
+}  // namespace kws
+
 extern "C" {
+
+int kws_model_set_precision(kws_model *m, int matrix, int infer)
+{
+    if (!m) return fail(KWS_ERR_INVALID, "null argument");
+    if (matrix != -1 && matrix != KWS_MATRIX_FP32 && matrix != KWS_MATRIX_BF16X6) return fail(KWS_ERR_INVALID, "unknown matrix precision %d", matrix);
+    if (infer != -1 && infer != KWS_INFER_FP32 && infer != KWS_INFER_FP16) return fail(KWS_ERR_INVALID, "unknown inference precision %d", infer);
+    m->matrix_precision = matrix;
+    m->infer_precision = infer;
+    return KWS_OK;
+}
+
+int kws_model_get_precision(const kws_model *m, int *matrix, int *infer)
+{
+    if (!m) return fail(KWS_ERR_INVALID, "null argument");
+    if (matrix) *matrix = matrix_prec(m);
+    if (infer) *infer = infer_prec(m);
+    return KWS_OK;
+}
+
+int kws_model_set_deterministic(kws_model *m, int on)
+{
+    if (!m) return fail(KWS_ERR_INVALID, "null argument");
+    if (on && (m->kind == KWS_SIMPLE_GRU || m->kind == KWS_SIMPLE_LSTM))
+        return fail(KWS_ERR_UNSUPPORTED, "the deterministic weight-gradient mode covers simple_cnn and simple_cnn_lite");
+    m->deterministic = on ? 1 : 0;
+    return KWS_OK;
+}
 
 int kws_model_create(int kind, int num_classes, int n_features, int feature_size, kws_model **out)
 {
@@ -997,7 +1103,7 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
     int rc = check_ws(m, B, false, ws, ws_bytes, w);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (m->kind == KWS_SIMPLE_CNN_LITE && g_infer_precision == KWS_INFER_FP16)
+    if (m->kind == KWS_SIMPLE_CNN_LITE && infer_prec(m) == KWS_INFER_FP16)
         return lite_forward_f16(m, feat, B, params, state, w, probs, argmax, s);
     rc = m->kind == KWS_SIMPLE_CNN_LITE ? lite_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s)
                                         : cnn_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s);

@@ -1,6 +1,8 @@
 // csrc/kws_model_types.h -- model descriptor shared by the CNN and RNN translation units.
 #pragma once
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -13,6 +15,13 @@ struct Tensor {
     std::vector<int> shape;
     bool trainable;
     int64_t offset, size;
+};
+
+// Streams and events a model's train step forks onto (weight gradients beside the data-gradient chain).  Owned by the
+// model -- two models, or one model per host thread and device, never share an event that one of them re-records.
+struct ModelRes {
+    hipStream_t side = nullptr;
+    hipEvent_t ev[16] = {nullptr};
 };
 
 struct CnnDims { int H0, W0, H1, W1, H2, W2, H3, W3, H4, W4, flat; };
@@ -38,6 +47,13 @@ struct WsCarver {
 
 struct kws_model {
     int kind, C, n_features, feature_size;
+    // -1: follow the library-wide default (kws_set_matrix_precision / kws_set_inference_precision); else the model's own
+    int matrix_precision = -1, infer_precision = -1;
+    int deterministic = 0;       // 1: weight gradients reduced in a fixed order (kws_model_set_deterministic)
+    std::mutex res_mu;
+    std::map<int, kws::ModelRes> res;   // per device, created on first use
+    kws::ModelRes *dev_res();           // resources for the CURRENT device (nullptr on failure)
+    ~kws_model();
     std::vector<kws::Tensor> tensors;
     int64_t P = 0, S = 0;
     kws::CnnDims d{};
@@ -74,7 +90,7 @@ int run_head(const kws_model *m, int B, const float *params, const float *x, flo
 bool head_bwd_fuses(const kws_model *m);
 int run_head_bwd(const kws_model *m, int B, const float *params, const float *x, const float *dlogits, float *dx,
                  float *grads, bool relu6_gate, hipStream_t s, float *dx_colsum = nullptr, const float *loss_i = nullptr,
-                 const float *correct_i = nullptr, float *stats = nullptr);
+                 const float *correct_i = nullptr, float *stats = nullptr, bool deterministic = false);
 
 // simple_gru (kws_rnn.hip)
 size_t gru_workspace_bytes(const kws_model *m, int B, bool training);

@@ -14,8 +14,9 @@ class InferenceSession(object):
             raise _l.KwsError(-3, "no HIP device: inference has no CPU fallback")
         self.dm, self.feat, self.batch = device_model, featurizer, int(batch)
         # fp16=True: simple_cnn_lite forward with fp16 activations / matrix operands, fp32 accumulation (BASELINE configs[4]);
-        # the library switch is read when the kernels are enqueued, so it is set around every eager run and the capture
+        # a per-model attribute (kws_model_set_precision), so sessions of different precisions coexist in one process
         self.precision = _l.INFER_FP16 if fp16 else _l.INFER_FP32
+        device_model.set_precision(infer=self.precision)
         g = featurizer.geometry
         samples = int(samples or g["max_samples"])
         wav_dtype = wav_dtype or torch.float32
@@ -34,12 +35,7 @@ class InferenceSession(object):
 
     def _eager(self):
         self.feat(self.wav, out=self.features)
-        before = _l.get_inference_precision()
-        _l.set_inference_precision(self.precision)
-        try:
-            self.probs, self.argmax = self.dm.forward(self.features)
-        finally:
-            _l.set_inference_precision(before)
+        self.probs, self.argmax = self.dm.forward(self.features)
 
     def run(self):
         if self._graph is not None:

@@ -110,6 +110,18 @@ def get_lib():
     L.kws_get_matrix_precision.restype = i32
     L.kws_set_inference_precision.argtypes = [i32]
     L.kws_get_inference_precision.restype = i32
+    L.kws_model_set_precision.argtypes = [vp, i32, i32]
+    L.kws_model_get_precision.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.kws_model_set_deterministic.argtypes = [vp, i32]
+    L.kws_comm_unique_id.argtypes = [vp]
+    L.kws_comm_init.argtypes = [i32, i32, vp, ctypes.POINTER(vp)]
+    L.kws_comm_destroy.argtypes = [vp]
+    L.kws_comm_destroy.restype = None
+    L.kws_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.kws_allreduce_grads.argtypes = [vp, vp, i64, i64, vp, vp, i64, f32, vp]
+    L.kws_comm_allreduce.argtypes = [vp, vp, i64, i32, i32, vp]
+    L.kws_comm_timing.argtypes = [vp, i32]
+    L.kws_comm_last_us.argtypes = [vp, ctypes.POINTER(f32), ctypes.POINTER(f32)]
     L.kws_prof_enable.argtypes = [i32]
     L.kws_prof_report.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.kws_prof_report.restype = i64
@@ -132,10 +144,14 @@ def device_count():
 
 MATRIX_FP32, MATRIX_BF16X6 = 0, 1
 INFER_FP32, INFER_FP16 = 0, 1
+COMM_ID_BYTES = 128
+DT_F32, DT_F64, DT_I32, DT_I64 = 0, 1, 2, 3
+OP_SUM, OP_MAX, OP_AVG = 0, 1, 2
 
 
 def set_matrix_precision(mode):
-    """MATRIX_BF16X6 (default: three-way bf16 split on the matrix cores, fp32-level error) or MATRIX_FP32 (exact fp32 MFMA)."""
+    """Library-wide DEFAULT (a model follows it until DeviceModel.set_precision gives it its own): MATRIX_BF16X6
+    (three-way bf16 split on the matrix cores, fp32-level error) or MATRIX_FP32 (exact fp32 MFMA)."""
     check(get_lib().kws_set_matrix_precision(int(mode)))
 
 

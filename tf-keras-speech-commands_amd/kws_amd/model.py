@@ -74,6 +74,7 @@ class DeviceModel(object):
         self.grads, self.adam_m, self.adam_v = z(spec.param_count), z(spec.param_count), z(spec.param_count)
         self.stats = torch.zeros((2,), dtype=torch.float32, device=self.device)
         self.step_count = 0
+        self._matrix = self._infer = None      # per-model precision attributes (None: library default)
         self._ws = None
         self._ws_key = None
 
@@ -107,6 +108,27 @@ class DeviceModel(object):
         """gradients of the trainable tensors, Keras trainable_weights order"""
         g = self.grads.cpu().numpy()
         return [g[t["offset"]:t["offset"] + t["size"]].reshape(t["shape"]).copy() for t in self.spec.tensors if t["trainable"]]
+
+    # ---- per-model switches ----------------------------------------------------------------------------------
+    def set_precision(self, matrix="keep", infer="keep"):
+        """This model's own arithmetic (kws_model_set_precision): matrix in {MATRIX_FP32, MATRIX_BF16X6}, infer in
+        {INFER_FP32, INFER_FP16}; None = follow the library-wide default again; "keep" leaves the attribute as it is."""
+        if matrix != "keep":
+            self._matrix = None if matrix is None else int(matrix)
+        if infer != "keep":
+            self._infer = None if infer is None else int(infer)
+        _l.check(self._L.kws_model_set_precision(self.spec.handle, -1 if self._matrix is None else self._matrix,
+                                                 -1 if self._infer is None else self._infer))
+
+    def get_precision(self):
+        """effective (matrix, infer) precision of this model"""
+        m, i = ctypes.c_int(), ctypes.c_int()
+        _l.check(self._L.kws_model_get_precision(self.spec.handle, ctypes.byref(m), ctypes.byref(i)))
+        return m.value, i.value
+
+    def set_deterministic(self, on=True):
+        """fixed-order weight-gradient reductions (bit-identical gradients run to run; for parity tests, slow)"""
+        _l.check(self._L.kws_model_set_deterministic(self.spec.handle, 1 if on else 0))
 
     # ---- compute ---------------------------------------------------------------------------------------------
     def _workspace(self, batch, training):

@@ -1,8 +1,17 @@
-"""Data-parallel exchange: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI; "gloo" on CPU
-for tests).  The train step shards the global batch across ranks; the only collective on the data path is the
-sum-all-reduce of the flat gradient buffer (134 932 floats for simple_cnn), issued as two buckets so that the first
-(conv4 + dense + head, 82 % of the bytes, produced first by the backward pass) overlaps the rest of the backward."""
+"""Data-parallel exchange: one process per GPU.
+
+The train step shards the global batch across ranks; the only collective on the data path is the sum-all-reduce of the
+flat gradient buffer (134 932 floats for simple_cnn), issued as two buckets so that the first (conv4 + dense + head, 82 %
+of the bytes, produced first by the backward pass) overlaps the rest of the backward.
+
+On GPUs the exchange goes through the C ABI (`kws_comm_*`, `kws_allreduce_grads`: RCCL over xGMI on the communicator's
+own stream, csrc/kws_comm.hip); torch.distributed is only the bootstrap (it ships the 128-byte RCCL id) and the control
+plane (barriers, logging sums).  CPU tensors (the gloo tests) take the torch.distributed path with the same bucket /
+weight arithmetic."""
+import ctypes
 import os
+
+from . import lib as _l
 
 
 def _dist():
@@ -34,18 +43,118 @@ def init_from_env(backend=None):
     d.init_process_group(backend, rank=int(os.environ["RANK"]), world_size=world)
 
 
+class KwsComm(object):
+    """Owner of a `kws_comm` handle (include/kws.h): an RCCL communicator on the current device plus its stream."""
+
+    def __init__(self, rank, world, unique_id):
+        self._L = _l.get_lib()
+        self._h = ctypes.c_void_p()
+        if len(unique_id) != _l.COMM_ID_BYTES:
+            raise ValueError("the RCCL unique id has %d bytes" % _l.COMM_ID_BYTES)
+        buf = ctypes.create_string_buffer(bytes(unique_id), _l.COMM_ID_BYTES)
+        _l.check(self._L.kws_comm_init(int(rank), int(world), buf, ctypes.byref(self._h)))
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        """128 bytes rank 0 creates and every rank passes to the constructor"""
+        buf = ctypes.create_string_buffer(_l.COMM_ID_BYTES)
+        _l.check(_l.get_lib().kws_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def from_torch_group(cls, group=None):
+        """Bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast as an object."""
+        d = _dist()
+        rank, world = d.get_rank(group), d.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        d.broadcast_object_list(box, src=d.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    @classmethod
+    def single(cls):
+        """a one-rank communicator (the same code path as N ranks; used by the 1-GPU tests)"""
+        return cls(0, 1, cls.unique_id())
+
+    @property
+    def rccl_version(self):
+        v = ctypes.c_int()
+        _l.check(self._L.kws_comm_info(self._h, None, None, ctypes.byref(v)))
+        return v.value
+
+    def allreduce_grads(self, grads, split=0, bucket_event=None, state=None, state_weight=1.0):
+        import torch
+        if bucket_event is not None and not bucket_event.cuda_event:
+            raise ValueError("bucket_event has not been recorded (pass the event given to train_fwd_bwd)")
+        _l.check(self._L.kws_allreduce_grads(self._h, grads.data_ptr(), grads.numel(), int(split or 0),
+                                             bucket_event.cuda_event if bucket_event is not None else None,
+                                             state.data_ptr() if state is not None else None,
+                                             state.numel() if state is not None else 0, float(state_weight),
+                                             torch.cuda.current_stream().cuda_stream))
+
+    def allreduce(self, t, op="sum"):
+        import torch
+        dt = {torch.float32: _l.DT_F32, torch.float64: _l.DT_F64, torch.int32: _l.DT_I32, torch.int64: _l.DT_I64}[t.dtype]
+        ro = {"sum": _l.OP_SUM, "max": _l.OP_MAX, "avg": _l.OP_AVG}[op]
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("kws_comm_allreduce needs a contiguous CUDA tensor")
+        _l.check(self._L.kws_comm_allreduce(self._h, t.data_ptr(), t.numel(), dt, ro, torch.cuda.current_stream().cuda_stream))
+        return t
+
+    def timing(self, on=True):
+        _l.check(self._L.kws_comm_timing(self._h, 1 if on else 0))
+
+    def last_us(self):
+        """(early bucket us, late bucket us) of the most recent allreduce_grads; None where not issued / not timed"""
+        a, b = ctypes.c_float(), ctypes.c_float()
+        _l.check(self._L.kws_comm_last_us(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return (a.value if a.value >= 0 else None, b.value if b.value >= 0 else None)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.kws_comm_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DataParallel(object):
-    def __init__(self, group=None):
+    """Sharding arithmetic + the per-step exchange.  `comm`: a KwsComm (GPU path through the C ABI).  Without one the
+    exchange uses torch.distributed on `group` (CPU tensors under gloo in the tests).  `force` makes a one-rank world
+    take the exchange path too (1-GPU test of the overlapped branch)."""
+
+    def __init__(self, group=None, comm=None, force=False):
         d = _dist()
         self.group = group
-        self.active = d.is_available() and d.is_initialized() and d.get_world_size(group) > 1
-        self.world = d.get_world_size(group) if self.active else 1
-        self.rank = d.get_rank(group) if self.active else 0
+        self.comm = comm
+        if comm is not None:
+            self.world, self.rank = comm.world, comm.rank
+            self.active = self.world > 1 or force
+            self._torch_dist = d.is_available() and d.is_initialized() and d.get_world_size(group) == self.world and self.world > 1
+        else:
+            self._torch_dist = d.is_available() and d.is_initialized() and d.get_world_size(group) > 1
+            self.active = self._torch_dist
+            self.world = d.get_world_size(group) if self.active else 1
+            self.rank = d.get_rank(group) if self.active else 0
         self._comm_stream = None
+
+    @classmethod
+    def for_device(cls, group=None):
+        """What `fit` uses: with an initialised multi-rank group and a GPU, an RCCL communicator behind the C ABI
+        bootstrapped over that group; else the plain torch.distributed path (or inactive)."""
+        import torch
+        d = _dist()
+        if d.is_available() and d.is_initialized() and d.get_world_size(group) > 1 and torch.cuda.is_available():
+            return cls(group, comm=KwsComm.from_torch_group(group))
+        return cls(group)
 
     @property
     def grad_scale(self):
-        """each rank scales its gradient of the LOCAL mean loss by 1/world, so the summed result is the global mean"""
+        """equal shards: each rank scales its gradient of the LOCAL mean loss by 1/world, so the sum is the global mean"""
         return 1.0 / self.world
 
     def shard(self, n):
@@ -54,10 +163,23 @@ class DataParallel(object):
         lo = min(n, self.rank * per)
         return lo, min(n, lo + per)
 
-    def sync_grads(self, grads, split=None, bucket_event=None):
-        """sum-all-reduce the flat gradient tensor.  With `split` and a recorded `bucket_event` (CUDA tensors only) the
-        early bucket grads[split:] is reduced on a side stream as soon as it is final."""
+    def shard_plan(self, n):
+        """(lo, hi, weight) for a global batch of n items: weight = local items / n is BOTH this rank's grad_scale (its
+        local-mean gradient times weight, summed over ranks, is the gradient of the global-batch mean even when the
+        last batch splits unevenly) and its weight in the mean of the BatchNormalization moving statistics.  An empty
+        shard has weight 0: that rank contributes zeros and only keeps the collective count equal."""
+        lo, hi = self.shard(n)
+        return lo, hi, (hi - lo) / float(n) if n > 0 else 0.0
+
+    def sync_grads(self, grads, split=None, bucket_event=None, state=None, state_weight=None):
+        """In-place sum over ranks of the flat gradient tensor, early bucket grads[split:] overlapped with the rest of
+        the backward pass when `bucket_event` is given; `state` (BatchNormalization moving statistics) becomes its
+        weighted mean over ranks in the same exchange (state_weight defaults to 1/world)."""
         if not self.active:
+            return
+        w = (1.0 / self.world) if state_weight is None else float(state_weight)
+        if self.comm is not None and grads.is_cuda:
+            self.comm.allreduce_grads(grads, split or 0, bucket_event, state, w)
             return
         d = _dist()
         if grads.is_cuda and split and bucket_event is not None:
@@ -70,22 +192,31 @@ class DataParallel(object):
                 d.all_reduce(grads[split:], group=self.group)
             d.all_reduce(grads[:split], group=self.group)          # late bucket, after the backward on the main stream
             main.wait_stream(self._comm_stream)
+        elif split:
+            d.all_reduce(grads[split:], group=self.group)          # same two buckets, in order (CPU tensors)
+            d.all_reduce(grads[:split], group=self.group)
         else:
             d.all_reduce(grads, group=self.group)
+        if state is not None:
+            state.mul_(w)
+            d.all_reduce(state, group=self.group)
 
     def mean_(self, tensor):
-        """in-place mean over ranks (BatchNormalization moving statistics, logged metrics)"""
+        """in-place mean over ranks (logged metrics)"""
         if self.active:
-            _dist().all_reduce(tensor, group=self.group)
+            self.sum_(tensor)
             tensor /= self.world
         return tensor
 
     def sum_(self, tensor):
-        if self.active:
-            _dist().all_reduce(tensor, group=self.group)
+        if not self.active:
+            return tensor
+        if self.comm is not None and tensor.is_cuda:
+            return self.comm.allreduce(tensor, "sum")
+        _dist().all_reduce(tensor, group=self.group)
         return tensor
 
     def broadcast_(self, tensor, src=0):
-        if self.active:
+        if self._torch_dist:
             _dist().broadcast(tensor, src, group=self.group)
         return tensor

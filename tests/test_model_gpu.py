@@ -632,3 +632,106 @@ def test_other_geometries_train_and_infer(torch, model_type, nf, fs):
         # oracle): the float32 path leaves rounding noise of its summed terms there, hence an absolute floor for the lite model
         floor = 3e-5 if model_type == "simple_cnn_lite" else 0.0
         assert np.abs(g - w).max() <= 3e-4 * np.abs(w).max() + floor, (li, n, rel_err(g, w))
+
+
+def test_two_models_with_their_own_precisions(torch):
+    """kws_model_set_precision: precision is a model attribute, so an exact-fp32 model and a split-bf16 model interleave in one
+    process without touching a library-wide switch; each reproduces what the library default gave it alone (bit for bit in
+    the deterministic gradient mode)."""
+    from kws_amd import lib as L
+    C, B = 36, 64
+    x = features(B, 41)
+    y = np.random.default_rng(42).integers(0, C, B).astype(np.int32)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    ref = {}
+    try:
+        for mode in (L.MATRIX_BF16X6, L.MATRIX_FP32):          # reference runs through the library-wide default
+            L.set_matrix_precision(mode)
+            _, dm = build("simple_cnn", C)
+            dm.set_deterministic(True)
+            assert dm.get_precision() == (mode, L.INFER_FP32)
+            p = dm.train_fwd_bwd(xt, yt, want_probs=True)
+            ref[mode] = (p.clone(), dm.grads.clone())
+    finally:
+        L.set_matrix_precision(L.MATRIX_BF16X6)
+    _, a = build("simple_cnn", C)
+    _, b = build("simple_cnn", C)
+    a.set_deterministic(True)
+    b.set_deterministic(True)
+    a.set_precision(matrix=L.MATRIX_FP32)
+    b.set_precision(matrix=L.MATRIX_BF16X6)
+    L.set_matrix_precision(L.MATRIX_FP32)                      # the default no longer matters to either model
+    try:
+        assert a.get_precision()[0] == L.MATRIX_FP32 and b.get_precision()[0] == L.MATRIX_BF16X6
+        for _ in range(2):                                     # interleaved
+            pa = a.train_fwd_bwd(xt, yt, want_probs=True)
+            pb = b.train_fwd_bwd(xt, yt, want_probs=True)
+            assert torch.equal(pa, ref[L.MATRIX_FP32][0]) and torch.equal(a.grads, ref[L.MATRIX_FP32][1])
+            assert torch.equal(pb, ref[L.MATRIX_BF16X6][0]) and torch.equal(b.grads, ref[L.MATRIX_BF16X6][1])
+    finally:
+        L.set_matrix_precision(L.MATRIX_BF16X6)
+    assert not torch.equal(ref[L.MATRIX_FP32][1], ref[L.MATRIX_BF16X6][1])     # the two paths really differ (by rounding)
+    with pytest.raises(L.KwsError):
+        a.set_precision(matrix=5)
+    a.set_precision(matrix=None)                               # back to following the default
+    assert a.get_precision()[0] == L.MATRIX_BF16X6
+    # inference precision is per model too: an fp16 lite model next to an fp32 one
+    _, l16 = build("simple_cnn_lite", C)
+    _, l32 = build("simple_cnn_lite", C)
+    l16.set_precision(infer=L.INFER_FP16)
+    p16, _ = l16.forward(xt)
+    p32, _ = l32.forward(xt)
+    p16b, _ = l16.forward(xt)
+    assert L.get_inference_precision() == L.INFER_FP32 and l32.get_precision()[1] == L.INFER_FP32
+    assert torch.equal(p16, p16b) and not torch.equal(p16, p32)
+    np.testing.assert_allclose(p16.cpu().numpy(), p32.cpu().numpy(), atol=1e-3, rtol=0)
+
+
+def test_deterministic_mode_is_bit_reproducible(torch):
+    """kws_model_set_deterministic: two runs of the same step give identical gradient bits (the default mode adds per-block
+    partial sums with float atomics, whose order varies), and both modes agree to float32 rounding."""
+    C, B = 36, 200
+    x = features(B, 51)
+    y = np.random.default_rng(52).integers(0, C, B).astype(np.int32)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    for kind in ("simple_cnn", "simple_cnn_lite"):
+        _, dm = build(kind, C)
+        dm.train_fwd_bwd(xt, yt, dropout_seed=9)
+        g_atomic = dm.grads.clone()
+        dm.set_deterministic(True)
+        runs = []
+        for _ in range(3):
+            dm.train_fwd_bwd(xt, yt, dropout_seed=9)
+            runs.append(dm.grads.clone())
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), kind
+        scale = float(runs[0].abs().max())
+        assert float((runs[0] - g_atomic).abs().max()) < 1e-5 * scale, kind
+    from kws_amd import lib as L
+    _, gru = build("simple_gru", C)
+    with pytest.raises(L.KwsError):
+        gru.set_deterministic(True)
+
+
+def test_oversized_dense_map_is_reported_not_ignored(torch):
+    """A geometry whose last pooled map is more than 8 rows tall (here 140 frames -> H4 = 9) is outside what the data-gradient
+    kernels cover: the train step must FAIL (it used to return KWS_OK with the dense layer's input gradient never written)."""
+    from kws_amd import lib as L
+    from kws_amd.init import init_weights
+    from kws_amd.model import DeviceModel, ModelSpec
+    x = torch.randn((4, 140, 12), device="cuda")
+    y = torch.zeros((4,), dtype=torch.int32, device="cuda")
+    spec = ModelSpec("simple_cnn_lite", 5, 140, 12)
+    dm = DeviceModel(spec)
+    dm.set_weights(init_weights(spec, seed=0))
+    dm.forward(x)                                              # inference is fine at this geometry
+    with pytest.raises(L.KwsError) as e:
+        dm.train_fwd_bwd(x, y)
+    assert e.value.code == -2 and "dgrad" in str(e.value)
+    torch.cuda.synchronize()
+    spec = ModelSpec("simple_cnn", 5, 140, 12)
+    dm = DeviceModel(spec)
+    dm.set_weights(init_weights(spec, seed=0))
+    dm.set_precision(matrix=L.MATRIX_FP32)
+    with pytest.raises(L.KwsError):
+        dm.train_fwd_bwd(x, y)
+    torch.cuda.synchronize()

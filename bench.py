@@ -3,12 +3,18 @@
 
 A "step" is one pass of the hot path over one synthetic batch that is already resident in HBM:
     featurize (B x 16000 f32 waveforms -> B x 30 x 20 MFCC)  ->  simple_cnn forward (batch-stat BN, dropout)
-    -> loss -> backward -> [sum-all-reduce of the flat gradient buffer when N > 1] -> Keras-form Adam.
+    -> loss -> backward -> [two-bucket sum-all-reduce of the flat gradient buffer when N > 1, early bucket overlapped with the
+    rest of the backward pass, through the C ABI: kws_allreduce_grads] -> Keras-form Adam.
 Workload at N = 1: BASELINE.json configs[1] (simple_cnn, 36 logits = background + 35 Speech Commands v2 words,
 batch 4096, HIP featurizer + fwd/bwd + Adam).  Weak scaling: every rank keeps B = 4096.
 
-Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel, measured
-live with HIP events on the launch stream (kws_prof_*), and `cpu_baseline` = the CPU oracle timed on the host cores.
+Output: ONE JSON line on rank 0 (contract in the task statement) with
+  roofline      the step's dominant kernel, timed live with HIP events on its launch stream (kws_prof_*)
+  cpu_baseline  the same step on the host cores: torch-CPU operators (stand-in for TF-Keras CPU, which this image lacks) behind
+                the C featurizer oracle, plus the rows SURVEY.md 8(d) lists (reference-plumbing numpy featurizer, bs 512 / 5 classes)
+  extra         the other SURVEY.md 8(d) workloads measured in the same run (N = 1 only): featurize + simple_cnn inference forward
+                (the north star's HBM-roofline target), simple_gru train step, simple_cnn_lite fp16 hipGraph forward, the train
+                step with exact-fp32 MFMA products, and the dense head's matrix-core figures.
 """
 import argparse
 import json
@@ -25,9 +31,14 @@ for _p in (ROOT, PKG):
 import numpy as np  # noqa: E402
 
 METRIC = "1 s@16 kHz clips/sec train-step, simple_cnn bs4096, 1/2/4/8 MI355X; eval top-1"
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak
 N_CLASSES = 36
+FWD_BYTES_PER_CLIP = 64144.0   # 64 000 B waveform in + 36 x 4 B probabilities out (features stay on chip)
+FEAT_BYTES_PER_CLIP = 66400.0  # featurizer alone, 64 000 in + 2 400 out
+TRAFFIC_RECORD = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_RECORD = os.path.join(ROOT, "profiles", "r02_pmc_dense_head.json")
 
 
 def synthetic_batch(B, rank, n_classes):
@@ -45,21 +56,15 @@ def synthetic_batch(B, rank, n_classes):
 
 def kernel_models(B, C):
     """Algorithmic work per launch of every kernel of the step (DESIGN.md section 'Kernels'):
-    name -> (bound, amount, unit) with bytes for HBM-bound kernels and flops for MFMA-bound ones."""
+    name -> (bound, amount) with bytes for HBM-bound kernels and flops for MFMA-bound ones."""
     f = 4
     z = [30 * 20 * 16, 15 * 10 * 32, 4 * 3 * 64, 4 * 3 * 128]          # pre-BN conv outputs per clip
     a = [15 * 10 * 16, 7 * 5 * 32, 4 * 3 * 64, 256]                    # activations per clip
     m = {}
-    m["featurize_fft1024_f32"] = ("hbm", B * 66400.0)                   # SURVEY 8(d): 64000 in + 2400 out
+    m["featurize_fft1024_f32"] = ("hbm", B * FEAT_BYTES_PER_CLIP)
     # layer 1 is recomputed from the feature map (kws_layer1.h): bytes = features (+ a1 / da1), never a z1-sized tensor
-    m["l1_stats_kernel"] = ("hbm", B * 600.0 * f)
-    m["l1_act_pool_kernel"] = ("hbm", B * (600 + a[0]) * f)
-    m["l1_bwd_reduce_kernel"] = ("hbm", B * (600 + a[0]) * f)
-    m["l1_bwd_wgrad_kernel"] = ("hbm", B * (600 + a[0]) * f)
-    m["l1m_stats_kernel"] = m["l1_stats_kernel"]                      # the MFMA, wave-per-clip forms of the same passes
-    m["l1m_act_pool_kernel"] = m["l1_act_pool_kernel"]
-    m["l1m_bwd_reduce_kernel"] = m["l1_bwd_reduce_kernel"]
-    m["l1m_bwd_wgrad_kernel"] = m["l1_bwd_wgrad_kernel"]
+    for k, v in (("stats", 600.0), ("act_pool", 600 + a[0]), ("bwd_reduce", 600 + a[0]), ("bwd_wgrad", 600 + a[0])):
+        m["l1_%s_kernel" % k] = m["l1m_%s_kernel" % k] = ("hbm", B * v * f)
     convs = {"16,32": (150, 9 * 16 * 32), "32,64": (12, 9 * 32 * 64), "64,128": (12, 9 * 64 * 128), "128,128": (1, 256 * 128)}
     for k, (pix, kn) in convs.items():
         m["conv_gemm_fwd<%s>" % k] = ("mfma", 2.0 * B * pix * kn)
@@ -73,14 +78,15 @@ def kernel_models(B, C):
     # dgrad kernels are named <reduced channels, produced channels>; algorithmic = the useful MACs of the layer
     m["conv_dgrad<32,16>"] = ("mfma", 2.0 * B * 150 * 9 * 16 * 32)
     m["conv_dgrad<64,32>"] = ("mfma", 2.0 * B * 12 * 9 * 32 * 64)         # one launch over the four stride-2 parity classes
-    # conv2 runs in the clip-resident LDS kernels (kws_conv.h: conv_fwd_clip / conv_dgrad_clip / conv_wgrad_clip)
-    # (fp32 MFMA) and their three-way bf16 split forms (default precision)
     for k in ("conv_fwd_clip<16,32>", "conv_wgrad_clip<16,32>", "conv_dgrad_clip<32,16>", "conv_fwd_clip_bf16<16,32>",
               "conv_wgrad_clip_bf16<16,32>", "conv_dgrad_clip_bf16<32,16>"):
         m[k] = ("mfma", 2.0 * B * 150 * 9 * 16 * 32)
+    m["conv_wgrad_bf16<32,64>"] = ("mfma", 2.0 * B * 12 * 9 * 32 * 64)
     m["conv_wgrad_bf16<64,128>"] = ("mfma", 2.0 * B * 12 * 9 * 64 * 128)
     m["conv_dgrad<128,64>"] = ("mfma", 2.0 * B * 12 * 9 * 64 * 128)
     m["conv_dgrad<128,128>"] = ("mfma", 2.0 * B * 256 * 128)
+    m["head_fwd_kernel"] = ("mfma", 2.0 * B * 128 * C)
+    m["head_bwd_kernel"] = ("mfma", 2.0 * 2.0 * B * 128 * C)              # dW2 and dx
     for l in range(1, 4):
         L = ".L%d" % (l + 1)
         m["channel_stats_kernel" + L] = ("hbm", B * z[l] * f)
@@ -92,28 +98,222 @@ def kernel_models(B, C):
     return m
 
 
-def cpu_baseline(sample_clips, steps, n_classes):
-    """The CPU oracle (kind 'port'): C featurizer (OpenMP over clips) + numpy float32 model step, on the host cores."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines (host cores of the GPU box; bounded samples).  oracle/ is used here as the thing TIMED BESIDE the GPU path,
+# never inside it.
+# ---------------------------------------------------------------------------------------------------------------------
+def log(msg):
+    """progress on stderr (the JSON line on stdout stays the only stdout output)"""
+    sys.stderr.write("[bench %s] %s\n" % (time.strftime("%H:%M:%S"), msg))
+    sys.stderr.flush()
+
+
+def usable_cores():
+    """CPUs this process may actually run on: the affinity mask capped by the cgroup CPU quota (a GPU box hands each GPU slot a
+    share of the host; os.cpu_count() reports the whole machine and oversubscribes thread pools badly)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, q // int(f2.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cap = os.environ.get("KWS_BENCH_CPU_THREADS")
+    if cap:
+        n = max(1, int(cap))
+    return n
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s):
+    import torch
     from oracle import featurizer_oracle as fo
     from oracle import model_oracle as mo
-    cores = os.cpu_count() or 1
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    wav, labels = synthetic_batch(sample_clips, 0, n_classes)
-    model = mo.Model("simple_cnn", n_classes, dtype=np.float32).init_weights(0)
-    opt = mo.Adam(1e-3)
+    from oracle import torch_ref as tr
+    cores = usable_cores()
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    torch.set_num_threads(cores)
+    log("cpu_baseline: %d usable cores of %d (%s)" % (cores, os.cpu_count() or 1, cpu_model()))
+    rows = {}
 
-    def step(i):
-        feat = fo.featurize_batch(wav)
-        mo.train_step(model, opt, feat, labels, dropout_seed=i + 1)
+    def time_steps(fn, max_steps, budget):
+        fn(0)                                                    # warm-up (thread pools, allocator)
+        t0 = time.time()
+        n = 0
+        while n < max_steps and (n == 0 or time.time() - t0 < budget):
+            fn(n + 1)
+            n += 1
+        return n, time.time() - t0
 
-    step(0)
-    t0 = time.time()
-    for i in range(steps):
-        step(i + 1)
-    dt = time.time() - t0
-    return {"value": sample_clips * steps / dt, "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "%d steps of %d synthetic clips (same generator as the GPU run) through oracle/: C featurizer with "
-                      "OpenMP over clips + numpy float32 simple_cnn fwd/bwd/Adam (BLAS threads = cores)" % (steps, sample_clips)}
+    def torch_train_row(model_type, B, C, with_featurizer):
+        wav, labels = synthetic_batch(B, 0, C)
+        base = mo.Model(model_type, C).init_weights(0)
+        flags = [t for _, _, t in base.weight_list()]
+        tm = tr.TorchModel(model_type, base.get_weights(), flags, dtype=torch.float32)
+        opt = tr.KerasAdam(1e-3)
+        feat0 = fo.featurize_batch(wav).astype(np.float32)
+        width = 256 if "cnn" in model_type else 20
+        rate = 0.5 if "cnn" in model_type else 0.2
+        rng = np.random.default_rng(7)
+
+        def step(i):
+            feat = fo.featurize_batch(wav).astype(np.float32) if with_featurizer else feat0
+            mask = ((rng.uniform(size=(B, width)) >= rate) / (1 - rate)).astype(np.float32)
+            tm.train_step(opt, feat, labels, None, mask)
+
+        n, dt = time_steps(step, 6, budget_s / 4.0)
+        log("cpu_baseline: %s B=%d C=%d featurizer=%s: %d steps in %.1f s" % (model_type, B, C, with_featurizer, n, dt))
+        return {"value": round(B * n / dt, 1), "unit": "clips/s", "kind": "port", "threads": cores,
+                "what": "%s train step (torch-CPU conv2d / batch_norm / max_pool2d / autograd, Keras-form Adam; oracle/torch_ref.py)%s, "
+                        "batch %d, %d classes, float32, %d steps" % (model_type, " behind the C featurizer oracle (OpenMP over clips)"
+                                                                      if with_featurizer else " on precomputed features (what the reference's fit consumes)",
+                                                                      B, C, n)}
+
+    # C3: the identical train step with torch-CPU operators, all cores -- the stand-in for "TF-Keras CPU"
+    rows["torch_cpu_step_bs4096_c36_with_featurizer"] = torch_train_row("simple_cnn", 4096, N_CLASSES, True)
+    rows["torch_cpu_step_bs4096_c36"] = torch_train_row("simple_cnn", 4096, N_CLASSES, False)
+    rows["torch_cpu_step_bs512_c5"] = torch_train_row("simple_cnn", 512, 5, False)          # BASELINE configs[0]
+    rows["torch_cpu_gru_step_bs2048_c36"] = torch_train_row("simple_gru", 2048, N_CLASSES, False)
+    # C2: single-thread per-clip numpy featurizer with the reference's plumbing (classifier/data.py:39-44 ->
+    # common/data_utils.py:61-86: keep-head / left-pad, list-comprehension framing, rfft, dense bank product rebuilt per call, scipy DCT)
+    wav, _ = synthetic_batch(256, 0, N_CLASSES)
+    torch.set_num_threads(1)
+
+    def numpy_clip(i):
+        a = wav[i % 256]
+        fo.numpy_mfcc(a[:16000])
+
+    n, dt = time_steps(numpy_clip, 2000, budget_s / 6.0)
+    torch.set_num_threads(cores)
+    rows["numpy_featurizer_per_clip_1thread"] = {"value": round(n / dt, 1), "unit": "clips/s", "kind": "port", "threads": 1,
+                                                 "what": "per-clip Python loop over oracle.featurizer_oracle.numpy_mfcc (the reference's plumbing: framing by list "
+                                                         "comprehension, np.fft.rfft, dense (30,513)x(513,20) bank product with the bank rebuilt per call, scipy DCT), %d clips" % n}
+    # C1: the C featurizer oracle, OpenMP over clips, all cores
+    wav4, _ = synthetic_batch(4096, 0, N_CLASSES)
+    n, dt = time_steps(lambda i: fo.featurize_batch(wav4), 4, budget_s / 6.0)
+    rows["c_featurizer_oracle_allcores"] = {"value": round(4096 * n / dt, 1), "unit": "clips/s", "kind": "port", "threads": cores,
+                                            "what": "oracle/kws_oracle.c (float64, OpenMP over clips), %d batches of 4096" % n}
+    head = rows["torch_cpu_step_bs4096_c36_with_featurizer"]
+    return {"value": head["value"], "unit": "clips/s", "cores": cores, "kind": "port", "cpu": cpu_model(), "host_cpus": os.cpu_count(),
+            "sample": "headline row = torch_cpu_step_bs4096_c36_with_featurizer: " + head["what"] + " (same generator as the GPU run; "
+                      "TensorFlow is not installed, torch-CPU operators stand in for TF-Keras CPU)", "rows": rows}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the other SURVEY 8(d) workloads, measured in the same run (N = 1)
+# ---------------------------------------------------------------------------------------------------------------------
+def time_graph(session, reps, torch):
+    for _ in range(3):
+        session.run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        session.run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def extra_workloads(torch, pr, feat_fn, reps):
+    import kws_amd.lib as L
+    from kws_amd.inference import InferenceSession
+    from kws_amd.init import init_weights
+    from kws_amd.model import DeviceModel, ModelSpec
+    from kws_amd.pipeline import FeaturePipeline
+    out = {}
+    # (i) featurize + simple_cnn inference forward, B = 4096: the north star's ">= 60 % of the HBM roofline" workload
+    wav_np, lab_np = synthetic_batch(4096, 0, N_CLASSES)
+    spec = ModelSpec("simple_cnn", N_CLASSES, pr.n_features, pr.feature_size)
+    dm = DeviceModel(spec)
+    dm.set_weights(init_weights(spec, seed=0))
+    s = InferenceSession(dm, feat_fn, 4096, use_graph=True)
+    s.wav.copy_(torch.from_numpy(wav_np))
+    ms = time_graph(s, reps, torch)
+    cps = 4096 / ms * 1e3
+    eager = InferenceSession(dm, feat_fn, 4096, use_graph=False)      # per-kernel times of the same forward, eager
+    eager.wav.copy_(s.wav)
+    L.prof_enable(True)
+    for _ in range(5):
+        eager.run()
+    rep = L.prof_report()
+    L.prof_enable(False)
+    log("extra: fwd_infer %.4f ms" % ms)
+    out["fwd_infer"] = {"workload": "featurize (f32 in) + simple_cnn inference forward, B = 4096, one hipGraph replay per batch", "ms": round(ms, 4),
+                        "clips_per_s": round(cps, 1), "hbm_roofline_clips_per_s": round(HBM_PEAK_GBS * 1e9 / FWD_BYTES_PER_CLIP, 1),
+                        "hbm_roofline_frac": round(cps * FWD_BYTES_PER_CLIP / (HBM_PEAK_GBS * 1e9), 4),
+                        "kernel_ms": {k: round(v["total_ms"] / 5, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}}
+    del s, eager, dm
+    # (iii) simple_gru train step, B = 2048 (BASELINE configs[2]): featurize + fwd + bwd + Adam, pipelined like the headline step
+    B = 2048
+    wav_np, lab_np = synthetic_batch(B, 0, N_CLASSES)
+    wav, labels = torch.from_numpy(wav_np).cuda(), torch.from_numpy(lab_np).cuda()
+    spec = ModelSpec("simple_gru", N_CLASSES, pr.n_features, pr.feature_size)
+    dm = DeviceModel(spec)
+    dm.set_weights(init_weights(spec, seed=0))
+    pipe = FeaturePipeline(feat_fn, B, pr.n_features, pr.feature_size)
+    ev = torch.cuda.Event()
+
+    def gru_steps(n, k0):
+        pipe.submit(wav)
+        for i in range(n):
+            feat = pipe.take()
+            dm.train_fwd_bwd(feat, labels, dropout_seed=k0 + i + 1, overlap_event=ev,
+                             overlap_callback=(lambda: pipe.submit(wav, after=ev)) if i + 1 < n else None)
+            dm.adam_step(1e-3)
+
+    gru_steps(5, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gru_steps(reps, 100)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    log("extra: gru_train %.4f ms" % ms)
+    out["gru_train"] = {"workload": "configs[2]: featurize + simple_gru fwd + bwd + Adam, B = 2048, 36 classes", "ms_per_step": round(ms, 4),
+                        "clips_per_s": round(B / ms * 1e3, 1), "final_loss": round(float(dm.stats[0].item()) / B, 4)}
+    del pipe, dm
+    # (iv) simple_cnn_lite fp16 inference, B = 16 384, hipGraph-captured featurize + forward (BASELINE configs[4])
+    B = 16384
+    spec = ModelSpec("simple_cnn_lite", N_CLASSES, pr.n_features, pr.feature_size)
+    lite = {}
+    wav_np, _ = synthetic_batch(B, 0, N_CLASSES)
+    for name, dt, nbytes in (("f32_in", torch.float32, 64144.0), ("pcm16_in", torch.int16, 32144.0)):
+        dm = DeviceModel(spec)
+        dm.set_weights(init_weights(spec, seed=0))
+        s = InferenceSession(dm, feat_fn, B, wav_dtype=dt, use_graph=True, fp16=True)
+        src = torch.from_numpy(wav_np)
+        s.wav.copy_(src if dt == torch.float32 else (src * 32768.0).to(torch.int16))
+        ms = time_graph(s, max(5, reps // 2), torch)
+        log("extra: lite fp16 %s %.4f ms" % (name, ms))
+        lite[name] = {"ms": round(ms, 4), "clips_per_s": round(B / ms * 1e3, 1), "bytes_per_clip": nbytes,
+                      "hbm_roofline_frac": round(B / ms * 1e3 * nbytes / (HBM_PEAK_GBS * 1e9), 4)}
+        del s, dm
+    lite["workload"] = "configs[4]: featurize + simple_cnn_lite forward, fp16 activations / matrix operands with fp32 accumulation, B = 16384, one hipGraph replay per batch"
+    out["lite_fp16_graph"] = lite
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -122,10 +322,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--cpu-clips", type=int, default=512)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-budget", type=float, default=16.0, help="seconds of CPU work for the cpu_baseline rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other SURVEY 8(d) workloads (extra.*)")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="run the RCCL exchange (kws_allreduce_grads) even in a one-rank world: rehearsal of the N > 1 code path on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -138,17 +340,19 @@ def main():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world)     # control plane: barriers, the max over ranks, the RCCL id
 
     import kws_amd
     from classifier.params import pr
+    from kws_amd import lib as L
     from kws_amd.featurizer import Featurizer
     from kws_amd.init import init_weights
     from kws_amd.model import DeviceModel, ModelSpec
+    from kws_amd.parallel import KwsComm
 
     B = args.batch
     feat_fn = Featurizer(pr)
@@ -158,10 +362,18 @@ def main():
     wav_np, lab_np = synthetic_batch(B, rank, N_CLASSES)
     wav = torch.from_numpy(wav_np).cuda()
     labels = torch.from_numpy(lab_np).cuda()
+    # data path collective: the C ABI's RCCL communicator (csrc/kws_comm.hip), bootstrapped over the torch group
+    comm = None
+    if world > 1:
+        comm = KwsComm.from_torch_group()
+    elif args.force_comm:
+        comm = KwsComm.single()
+    split = dm.grad_split
     from kws_amd.pipeline import FeaturePipeline
     pipe = FeaturePipeline(feat_fn, B, pr.n_features, pr.feature_size)
     step_no = [0]
     overlap_ev = torch.cuda.Event()
+    bucket_ev = torch.cuda.Event() if comm is not None else None
 
     def submit_next():
         pipe.submit(wav, after=overlap_ev)
@@ -178,13 +390,14 @@ def main():
             feat = pipe.take()
             # next batch's features on the side stream, started behind this step's last forward convolution: the library
             # records overlap_ev there and calls back, so the featurizer launch also sits at that point in HOST order
-            # (from there the main chain is small kernels, then matrix-bound ones)
             dm.train_fwd_bwd(feat, labels, dropout_seed=step_no[0], grad_scale=1.0 / world, overlap_event=overlap_ev,
-                             overlap_callback=submit_next if i + 1 < n else None)
+                             overlap_callback=submit_next if i + 1 < n else None, bucket_event=bucket_ev)
             # no pipe.release() here: the featurizer that rewrites this step's feature buffer (batch k+2) is ordered behind the NEXT
-            # step's overlap event on this stream, i.e. behind every kernel of this step -- the extra event would cost 6 us per step
-            if dist is not None:
-                dist.all_reduce(dm.grads)      # RCCL sum over xGMI; 540 KB flat buffer
+            # step's overlap event on this stream, i.e. behind every kernel of this step
+            if comm is not None:
+                # early bucket (conv4 + dense + head, 82 % of the bytes) on the communicator's stream as soon as the library's
+                # bucket event fires, late bucket + BatchNormalization statistics behind the backward pass; Adam waits for both
+                comm.allreduce_grads(dm.grads, split, bucket_ev, dm.state, 1.0 / world)
             dm.adam_step(1e-3)
 
     def fence():
@@ -192,8 +405,10 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    log("warm-up: %d steps" % args.warmup)
     run_steps(args.warmup)
     fence()
+    log("timed region: %d steps" % args.steps)
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
@@ -203,27 +418,41 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss = float(dm.stats[0].item()) / B
+    log("timed region done: %.4f ms/step" % (elapsed / args.steps * 1e3))
 
     # per-kernel timing on the launch stream (HIP events inside the library), separate from the timed region
     # (every rank runs these steps -- they contain the all-reduce -- but only rank 0 records and reports)
-    roofline, breakdown, breakdown_serial = None, {}, {}
+    roofline, breakdown, breakdown_serial, allreduce_us = None, {}, {}, None
     if args.profile_steps > 0:
         if rank == 0:
-            kws_amd.lib.prof_enable(True)
+            L.prof_enable(True)
         run_steps(args.profile_steps)          # the same pipelined execution as the timed region
         fence()
         if rank == 0:
-            rep = kws_amd.lib.prof_report()
-            kws_amd.lib.prof_enable(False)
-            kws_amd.lib.prof_enable(True)
+            rep = L.prof_report()
+            L.prof_enable(False)
+            L.prof_enable(True)
+        if comm is not None:
+            comm.timing(True)
+        ar = []
         for _ in range(args.profile_steps):    # and once more step by step, so that the featurizer runs alone: the
             run_steps(1)                       # per-kernel times of this pass are not stretched by sharing the chip
+            if comm is not None:
+                torch.cuda.synchronize()
+                ar.append(comm.last_us())
         fence()
+        if comm is not None:
+            comm.timing(False)
+            allreduce_us = {"early_bucket": round(float(np.mean([a[0] for a in ar if a[0] is not None] or [0.0])), 2),
+                            "late_bucket_with_bn_statistics": round(float(np.mean([a[1] for a in ar if a[1] is not None] or [0.0])), 2),
+                            "early_bucket_floats": int(dm.params.numel() - split), "late_bucket_floats": int(split),
+                            "how": "HIP events on the communicator's stream around each RCCL launch, mean over %d serial steps on rank 0" % len(ar)}
         if rank == 0:
-            rep_serial = kws_amd.lib.prof_report()
-            kws_amd.lib.prof_enable(False)
+            rep_serial = L.prof_report()
+            L.prof_enable(False)
             for k, v in sorted(rep_serial.items(), key=lambda kv: -kv[1]["total_ms"]):
                 breakdown_serial[k] = round(v["total_ms"] / args.profile_steps, 4)
+    dense_head = None
     if rank == 0 and args.profile_steps > 0:
         models = kernel_models(B, N_CLASSES)
         tot = sum(v["total_ms"] for v in rep.values())
@@ -236,25 +465,77 @@ def main():
             ach, peak, unit = amount / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
         else:
             ach, peak, unit = amount / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-        traffic = None       # HBM bytes per launch from the PMC passes recorded in profiles/ (bench.py cannot run rocprofv3 itself)
+        # HBM bytes per launch from the PMC passes recorded in profiles/ (bench.py cannot run rocprofv3 around itself); a record
+        # is only used if it was measured on the SAME source of the kernel's file as the loaded library was built from
+        traffic, traffic_note = None, "no PMC record for this kernel"
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                rec = json.load(f).get(name)
+            with open(TRAFFIC_RECORD) as f:
+                trec = json.load(f)
+            rec = trec.get(name)
             if rec and rec.get("batch") == B:
-                traffic = rec["traffic_bytes_per_launch"]
+                if rec.get("source_sha1") == L.build_id().get(rec.get("source_file")):
+                    traffic, traffic_note = rec["traffic_bytes_per_launch"], "profiles/%s" % os.path.basename(TRAFFIC_RECORD)
+                else:
+                    traffic_note = "PMC record is stale (measured on %s %s, library built from %s)" % (
+                        rec.get("source_file"), rec.get("source_sha1"), L.build_id().get(rec.get("source_file")))
         except (OSError, ValueError):
             pass
         alone_ms = rep_serial[name]["total_ms"] / rep_serial[name]["count"]
         roofline = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": traffic, "avg_launch_ms": round(avg_ms, 5),
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(avg_ms, 5),
                     "share_of_step_kernel_time": round(rep[name]["total_ms"] / tot, 3),
                     # the same kernel when nothing else shares the chip (second profile pass): the pipelined step runs it
                     # next to the model kernels, which stretches its launch but shortens the step
                     "alone_launch_ms": round(alone_ms, 5), "alone_frac": round(ach * avg_ms / alone_ms / peak, 4)}
+        # the dense head (Dense(256->128) as a 2x1 'valid' conv + Dense(C) softmax head), forward and backward: the only dense
+        # contractions of the model -> matrix-core figures (north star: "MFMA utilisation for the dense head")
+        dh = {}
+        fl_tot, ms_tot = 0.0, 0.0
+        for k in ("conv_bf16_fwd<128,128>", "conv_gemm_fwd<128,128>", "conv_bf16_dgrad<128,128>", "conv_dgrad<128,128>", "conv_wgrad<128,128>",
+                  "head_fwd_kernel", "head_bwd_kernel"):
+            if k in rep_serial and k in models:
+                ms_k = rep_serial[k]["total_ms"] / rep_serial[k]["count"]
+                dh[k] = {"ms": round(ms_k, 5), "algorithmic_tflops": round(models[k][1] / (ms_k * 1e-3) / 1e12, 3)}
+                fl_tot += models[k][1]
+                ms_tot += ms_k
+        pmc = None
+        try:
+            with open(PMC_RECORD) as f:
+                prec = json.load(f)
+            bid = L.build_id()
+            if all(bid.get(fn) == sha for fn, sha in prec.get("source_sha1", {}).items()):
+                pmc = prec.get("kernels")
+        except (OSError, ValueError):
+            pass
+        dense_head = {"kernels": dh, "algorithmic_tflops": round(fl_tot / (ms_tot * 1e-3) / 1e12, 3) if ms_tot else None,
+                      "frac_of_fp32_matrix_peak": round(fl_tot / (ms_tot * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if ms_tot else None,
+                      "note": "serial-pass HIP-event times; split-precision kernels issue 6 bf16 MFMA partial products per algorithmic MAC, so their "
+                              "matrix-pipe rate is 6x the algorithmic one (peak %.0f TFLOP/s bf16)" % MFMA_BF16_PEAK_TFLOPS,
+                      "mfma_busy_pmc": pmc}
+
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        log("extra workloads")
+        extra = extra_workloads(torch, pr, feat_fn, 30)
+        log("extra: fp32 MFMA step")
+        # the headline step with exact-fp32 MFMA products everywhere (KWS_MATRIX_FP32), same pipeline
+        dm.set_precision(matrix=L.MATRIX_FP32)
+        run_steps(10)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(50)
+        torch.cuda.synchronize()
+        ms32 = (time.perf_counter() - t1) / 50 * 1e3
+        dm.set_precision(matrix=None)
+        extra["fp32_mfma_step"] = {"workload": "the headline train step with every matrix product on v_mfma_f32_16x16x4_f32 (bit-exact fp32 fma chains)",
+                                   "ms_per_step": round(ms32, 4), "clips_per_s": round(B / ms32 * 1e3, 1)}
+        extra["dense_head_mfma"] = dense_head
+    elif rank == 0:
+        extra = {"dense_head_mfma": dense_head}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.cpu_clips, args.cpu_steps, N_CLASSES)
+        cpu = cpu_baseline(args.cpu_budget)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -266,13 +547,20 @@ def main():
                                       "36 logits (background + 35 words), batch %d per GPU" % B,
                           "global_batch": B * world, "parallelism": "dp%d" % world, "final_loss": round(loss, 4),
                           "matrix_precision": "conv2/conv3/conv4/dense products as three-way bf16 splits on the bf16 matrix cores "
-                                              "with fp32 accumulation (fp32-level error, kws_set_matrix_precision); conv1, conv3 "
-                                              "data/weight gradients, dense weight gradient and everything else fp32",
+                                              "with fp32 accumulation (fp32-level error, kws_model_set_precision); conv1, conv3 "
+                                              "data gradient, dense weight gradient and everything else fp32; extra.fp32_mfma_step is the all-fp32 number",
                           "input_pipeline": "features of batch k+1 computed on a side stream during step k, started behind the last forward convolution (kws_train_args.overlap_event; all K featurizations inside the timed region)",
-                          "train_step_hbm_roofline_frac": round(value / world * 229.8e3 / (HBM_PEAK_GBS * 1e9), 4)},
-               "roofline": roofline, "cpu_baseline": cpu, "kernel_ms_per_step": breakdown,
+                          "gradient_exchange": ("kws_allreduce_grads (RCCL behind the C ABI): early bucket grads[%d:] on the communicator's stream behind the library's bucket event, "
+                                                "late bucket + BN moving statistics grouped behind the backward pass, Adam waits for both" % split) if comm is not None else "none (one rank)",
+                          "allreduce_us": allreduce_us,
+                          "train_step_hbm_roofline_frac": round(value / world * 229.8e3 / (HBM_PEAK_GBS * 1e9), 4),
+                          "library_build": L.build_id().get("kws_featurize.hip")},
+               "roofline": roofline, "cpu_baseline": cpu, "extra": extra, "kernel_ms_per_step": breakdown,
                "kernel_ms_per_step_serial": breakdown_serial}
         print(json.dumps(out))
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
     if dist is not None:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()

@@ -38,6 +38,8 @@ typedef enum kws_status {
 } kws_status;
 
 const char *kws_version(void);
+/* "<source file>:<sha1 prefix>;..." of every file the library was built from (measurement records in profiles/ are tied to it) */
+const char *kws_build_id(void);
 const char *kws_last_error(void);
 /* number of visible HIP devices (0 when none / no driver); never fails */
 int kws_device_count(void);

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "kws_common.h"
+#include "kws_build_id.h"
 
 namespace kws {
 std::string &last_error_slot()
@@ -112,6 +113,8 @@ int64_t kws_prof_report(char *buf, size_t buflen)
 }
 
 const char *kws_version(void) { return "kws-amd 0.1.0 (gfx950)"; }
+
+const char *kws_build_id(void) { return KWS_BUILD_ID; }
 
 const char *kws_last_error(void) { return kws::last_error_slot().c_str(); }
 

@@ -63,6 +63,7 @@ def get_lib():
     vp, i32, i64, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
     L.kws_version.restype = ctypes.c_char_p
     L.kws_last_error.restype = ctypes.c_char_p
+    L.kws_build_id.restype = ctypes.c_char_p
     L.kws_device_count.restype = i32
     L.kws_params_default.argtypes = [ctypes.POINTER(KwsParams)]
     L.kws_params_default.restype = None
@@ -136,6 +137,16 @@ def check(rc):
 
 def version():
     return get_lib().kws_version().decode()
+
+
+def build_id():
+    """{source file: sha1 prefix} the loaded library was built from"""
+    out = {}
+    for item in get_lib().kws_build_id().decode().split(";"):
+        if item:
+            k, v = item.split(":")
+            out[k] = v
+    return out
 
 
 def device_count():

@@ -15,6 +15,7 @@
 //            the second touch is an L1/L2 hit issued by the same block, so DRAM traffic stays at
 //            the algorithmic 4 B/sample in + 4 B/feature out.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -54,6 +55,12 @@ struct FeatDev {
     const int *bfirst;   // [n_filt] first non-zero bin of each band
     const int *bwidth;   // [n_filt] span length
     const float *bw;     // [n_filt][n_bins] dense bank rows (float)
+    // second-generation kernel (kws_featurize_v2.h): chunks placed on even bins, split twiddles in the kernel's lane order
+    int chp2;
+    const int4 *chunks2; // [64 lanes] {band, first bin read (even), chunk id, 0}
+    const int *bcs2;     // [n_filt+1]
+    const float *w2;     // [64 lanes][chp2]
+    const float2 *tws2;  // [4][64]  W_1024^(ka(lane) + 64 i), ka(lane) = (lane >> 3) + 8 (lane & 7)
 };
 
 }  // namespace kws
@@ -492,6 +499,10 @@ __global__ __launch_bounds__(kGenWaves * 64) void featurize_generic_kernel(const
     }
 }
 
+}  // namespace kws
+#include "kws_featurize_v2.h"
+namespace kws {
+
 // ---------------------------------------------------------------------------------------------
 // host side: parameter geometry and table construction (double precision, then rounded once)
 // ---------------------------------------------------------------------------------------------
@@ -595,6 +606,41 @@ static int build_bark_bank(int sample_rate, int n_fft, int n_filt, std::vector<d
 
 using namespace kws;
 
+// second-generation kernel (kws_featurize_v2.h): default frame geometry, 20 bands, 20 coefficients, no deltas
+constexpr int kV2Bands = 20, kV2Coefs = 20;
+static bool v2_applies(const FeatDev &d)
+{
+    static const bool disabled = std::getenv("KWS_FEAT_V1") != nullptr;     // A/B switch for tools/ (not part of the API)
+    return !disabled && d.n_fft == 1024 && d.hop == 512 && d.window_eff == 1024 && !d.use_delta && d.n_filt == kV2Bands &&
+           d.n_out == kV2Coefs && (d.chp2 == 12 || d.chp2 == 16 || d.chp2 == 20);
+}
+static size_t v2_smem_bytes(int chp)
+{
+    constexpr int TB = 64 / kV2Bands;
+    return (size_t)kWaves * (kFftTile * 8 + 4 * (TB * 64 + 64 + 4)) + 4 * (size_t)(kV2Bands * kV2Coefs + 64 * chp) +
+           8 * (size_t)(7 * 64 + 7 * 8 + 4 * 64) + 4 * (size_t)round4(kV2Bands + 1);
+}
+template <typename WavT, int CHP>
+static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s,
+                     const char *name)
+{
+    const long jobs = (long)B * d.jpc;
+    KWS_LAUNCH(name, (featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs>), dim3((unsigned)((jobs + kWaves - 1) / kWaves)), dim3(kThreads),
+               v2_smem_bytes(CHP), s, wav, stride, valid_len, B, d, feat);
+    KWS_LAUNCH_CHECK("featurize_fft1024_v2_kernel");
+    return KWS_OK;
+}
+template <typename WavT>
+static int launch_v2_chp(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s,
+                         const char *name)
+{
+    switch (d.chp2) {
+    case 12: return launch_v2<WavT, 12>(d, wav, B, stride, valid_len, feat, s, name);
+    case 16: return launch_v2<WavT, 16>(d, wav, B, stride, valid_len, feat, s, name);
+    default: return launch_v2<WavT, 20>(d, wav, B, stride, valid_len, feat, s, name);
+    }
+}
+
 extern "C" {
 
 void kws_params_default(kws_params *p)
@@ -639,74 +685,93 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
             if (bank[(size_t)i * n_bins + j] != 0.0) { if (a < 0) a = j; z = j; }
         if (a >= 0) { first[i] = a; width[i] = z - a + 1; }
     }
-    int ch = 1;
-    for (;; ++ch) {
-        int cnt = 0;
-        for (int i = 0; i < n_filt; ++i) cnt += (width[i] + ch - 1) / ch;
-        if (cnt <= kMaxChunks) break;
-    }
-    const int chp = (ch + 3) & ~3, n_filt_pad = (n_filt + 3) & ~3;
-    // logical chunks in band order: (band, first bin, bins)
-    struct Chunk { int band, a, len; };
-    std::vector<Chunk> logical;
-    std::vector<int> bcs(n_filt + 1, 0);
-    for (int i = 0; i < n_filt; ++i) {
-        bcs[i] = (int)logical.size();
-        for (int off = 0; off < width[i]; off += ch) logical.push_back(Chunk{i, first[i] + off, std::min(ch, width[i] - off)});
-    }
-    bcs[n_filt] = (int)logical.size();
-    const int nlog = (int)logical.size();
-    // Lane placement.  Every lane reads p[start + t] for the same t, so the 32 lanes of a half-wave hit 32 different LDS
-    // banks iff their starts differ mod 32.  A chunk of `len` bins may start anywhere in [a + len - chp, a] (the extra bins
-    // get zero weights), so: bipartite matching of chunks to the 64 (half, residue) slots, lane = 32 * half + residue.
-    // (Chunk starts taken as they come collide ~3-way on average: 29 % of the kernel's LDS cycles were conflicts.)
-    std::vector<int> slot_of(nlog, -1), start_of(nlog, 0), owner(64, -1);
-    {
-        std::vector<std::vector<std::pair<int, int>>> cand(nlog);          // (slot, start)
-        for (int c = 0; c < nlog; ++c)
-            for (int st = logical[c].a; st >= std::max(0, logical[c].a + logical[c].len - chp); --st)
-                for (int h = 0; h < 2; ++h) cand[c].push_back({32 * h + (st & 31), st});
-        std::vector<int> owner_start(64, 0);
-        std::function<bool(int, std::vector<char> &)> place = [&](int c, std::vector<char> &seen) -> bool {
-            for (auto &e : cand[c]) {
-                if (seen[e.first]) continue;
-                seen[e.first] = 1;
-                if (owner[e.first] < 0 || place(owner[e.first], seen)) {
-                    owner[e.first] = c; owner_start[e.first] = e.second;
-                    return true;
-                }
+    // Chunk tables for the sparse band gather.  `align` = 1: a lane reads its bins one per LDS instruction (first-generation
+    // kernel); 2: chunks start on even bins so that two bins come per ds_read_b64 (kws_featurize_v2.h).
+    struct ChunkTables { int ch, chp, nlog; std::vector<int4> chunks; std::vector<float> w; std::vector<int> bcs; };
+    auto build_chunks = [&](int align) {
+        ChunkTables T;
+        int ch = align;
+        for (;; ch += align) {
+            int cnt = 0;
+            for (int i = 0; i < n_filt; ++i) cnt += (width[i] + (first[i] % align) + ch - 1) / ch;
+            if (cnt <= kMaxChunks) break;
+        }
+        const int chp = (ch + 3) & ~3;
+        // logical chunks in band order: (band, first bin, bins); chunk boundaries sit on multiples of `align`
+        struct Chunk { int band, a, len; };
+        std::vector<Chunk> logical;
+        std::vector<int> bcs(n_filt + 1, 0);
+        for (int i = 0; i < n_filt; ++i) {
+            bcs[i] = (int)logical.size();
+            const int s0 = first[i] - first[i] % align, end = first[i] + width[i];
+            for (int lo = s0; lo < end; lo += ch) {
+                const int a = std::max(lo, first[i]), z = std::min(lo + ch, end);
+                if (z > a) logical.push_back(Chunk{i, a, z - a});
             }
-            return false;
-        };
-        bool perfect = true;
-        for (int c = 0; c < nlog && perfect; ++c) {
-            std::vector<char> seen(64, 0);
-            perfect = place(c, seen);
         }
-        if (perfect) {
-            for (int sl = 0; sl < 64; ++sl)
-                if (owner[sl] >= 0) { slot_of[owner[sl]] = sl; start_of[owner[sl]] = owner_start[sl]; }
-        } else {                                                           // keep the natural order (correct, just slower)
-            std::fill(owner.begin(), owner.end(), -1);
-            for (int c = 0; c < nlog; ++c) { slot_of[c] = c; start_of[c] = logical[c].a; owner[c] = c; }
+        bcs[n_filt] = (int)logical.size();
+        const int nlog = (int)logical.size();
+        // Lane placement.  Every lane reads p[start + t] for the same t, so the 32 lanes of a half-wave hit different LDS banks
+        // iff their starts (in units of `align` bins) differ mod 32.  A chunk of `len` bins may start anywhere (on a multiple
+        // of `align`) in [a + len - chp, a] (the extra bins get zero weights), so: bipartite matching of chunks to the 64
+        // (half, residue) slots, lane = 32 * half + residue.  (Chunk starts taken as they come collide ~3-way on average:
+        // 29 % of the first kernel's LDS cycles were conflicts.)
+        std::vector<int> start_of(nlog, 0), owner(64, -1);
+        {
+            std::vector<std::vector<std::pair<int, int>>> cand(nlog);          // (slot, start)
+            for (int c = 0; c < nlog; ++c)
+                for (int st = logical[c].a - logical[c].a % align; st >= std::max(0, logical[c].a + logical[c].len - chp); st -= align)
+                    for (int h = 0; h < 2; ++h) cand[c].push_back({32 * h + ((st / align) & 31), st});
+            std::vector<int> owner_start(64, 0);
+            std::function<bool(int, std::vector<char> &)> place = [&](int c, std::vector<char> &seen) -> bool {
+                for (auto &e : cand[c]) {
+                    if (seen[e.first]) continue;
+                    seen[e.first] = 1;
+                    if (owner[e.first] < 0 || place(owner[e.first], seen)) {
+                        owner[e.first] = c; owner_start[e.first] = e.second;
+                        return true;
+                    }
+                }
+                return false;
+            };
+            bool perfect = nlog <= 64;
+            for (int c = 0; c < nlog && perfect; ++c) {
+                std::vector<char> seen(64, 0);
+                perfect = place(c, seen);
+            }
+            if (perfect) {
+                for (int sl = 0; sl < 64; ++sl)
+                    if (owner[sl] >= 0) start_of[owner[sl]] = owner_start[sl];
+            } else {                                                           // keep the natural order (correct, just slower)
+                std::fill(owner.begin(), owner.end(), -1);
+                for (int c = 0; c < nlog && c < 64; ++c) { start_of[c] = logical[c].a - logical[c].a % align; owner[c] = c; }
+            }
         }
-    }
-    // per-lane tables (always 64 lanes): {band, start, chunk id, 0} and chp weights; idle lanes take the unused chunk ids
-    std::vector<int4> chunks(64);
-    std::vector<float> w((size_t)64 * chp, 0.f);
-    {
+        // per-lane tables (always 64 lanes): {band, start, chunk id, 0} and chp weights; idle lanes take the unused chunk ids
+        T.chunks.assign(64, make_int4(0, 0, 0, 0));
+        T.w.assign((size_t)64 * chp, 0.f);
         int spare = nlog;
         for (int lane = 0; lane < 64; ++lane) {
             const int c = owner[lane];
-            if (c < 0) { chunks[lane] = make_int4(0, 0, spare < 64 ? spare++ : 63, 0); continue; }
-            chunks[lane] = make_int4(logical[c].band, start_of[c], c, 0);
+            if (c < 0) { T.chunks[lane] = make_int4(0, 0, spare < 64 ? spare++ : 63, 0); continue; }
+            T.chunks[lane] = make_int4(logical[c].band, start_of[c], c, 0);
             for (int t = 0; t < chp; ++t) {
                 const int bin = start_of[c] + t;
                 if (bin >= logical[c].a && bin < logical[c].a + logical[c].len)
-                    w[(size_t)lane * chp + t] = (float)bank[(size_t)logical[c].band * n_bins + bin];
+                    T.w[(size_t)lane * chp + t] = (float)bank[(size_t)logical[c].band * n_bins + bin];
             }
         }
-    }
+        T.ch = ch; T.chp = chp; T.nlog = nlog; T.bcs = bcs;
+        return T;
+    };
+    const ChunkTables T1 = build_chunks(1), T2 = build_chunks(2);
+    if (std::getenv("KWS_FEAT_DEBUG"))
+        fprintf(stderr, "[kws] featurizer tables: chunk %d (padded %d, %d chunks) / even-aligned chunk %d (padded %d, %d chunks)\n", T1.ch, T1.chp,
+                T1.nlog, T2.ch, T2.chp, T2.nlog);
+    const int chp = T1.chp, nlog = T1.nlog, n_filt_pad = (n_filt + 3) & ~3;
+    const std::vector<int4> &chunks = T1.chunks;
+    const std::vector<float> &w = T1.w;
+    const std::vector<int> &bcs = T1.bcs;
 
     std::vector<float2> tw1(7 * 64), tw2(7 * 8), tws(257);
     for (int k = 1; k < 8; ++k)
@@ -723,6 +788,12 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
         const double a = -2.0 * M_PI * (double)k / 1024.0;
         tws[k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
+    std::vector<float2> tws2(4 * 64);
+    for (int i = 0; i < 4; ++i)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * M_PI * (double)(v2_ka(l) + 64 * i) / 1024.0;
+            tws2[i * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
     // generic-path tables (used when n_fft != 1024)
     std::vector<float2> twg((size_t)p->n_fft / 2);
     for (int k = 0; k < p->n_fft / 2; ++k) {
@@ -752,7 +823,8 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
                  o_ch = al(o_tws + tws.size() * 8), o_bcs = al(o_ch + std::max<size_t>(1, chunks.size()) * 16),
                  o_w = al(o_bcs + bcs.size() * 4), o_dct = al(o_w + std::max<size_t>(1, w.size()) * 4),
                  o_twg = al(o_dct + dct.size() * 4), o_bf = al(o_twg + twg.size() * 8), o_bwd = al(o_bf + first.size() * 4),
-                 o_bw = al(o_bwd + width.size() * 4), total = al(o_bw + bwf.size() * 4);
+                 o_bw = al(o_bwd + width.size() * 4), o_ch2 = al(o_bw + bwf.size() * 4), o_bcs2 = al(o_ch2 + 64 * 16),
+                 o_w2 = al(o_bcs2 + T2.bcs.size() * 4), o_tws2 = al(o_w2 + T2.w.size() * 4), total = al(o_tws2 + tws2.size() * 8);
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + o_tw1, tw1.data(), tw1.size() * 8);
     std::memcpy(host.data() + o_tw2, tw2.data(), tw2.size() * 8);
@@ -765,6 +837,10 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     std::memcpy(host.data() + o_bf, first.data(), first.size() * 4);
     std::memcpy(host.data() + o_bwd, width.data(), width.size() * 4);
     std::memcpy(host.data() + o_bw, bwf.data(), bwf.size() * 4);
+    std::memcpy(host.data() + o_ch2, T2.chunks.data(), 64 * 16);
+    std::memcpy(host.data() + o_bcs2, T2.bcs.data(), T2.bcs.size() * 4);
+    std::memcpy(host.data() + o_w2, T2.w.data(), T2.w.size() * 4);
+    std::memcpy(host.data() + o_tws2, tws2.data(), tws2.size() * 8);
     hipError_t e = hipMalloc(&f->dmem, total);
     if (e == hipSuccess) e = hipMemcpy(f->dmem, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -794,6 +870,11 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     d.bfirst = reinterpret_cast<const int *>(base + o_bf);
     d.bwidth = reinterpret_cast<const int *>(base + o_bwd);
     d.bw = reinterpret_cast<const float *>(base + o_bw);
+    d.chp2 = T2.nlog <= 64 ? T2.chp : 0;
+    d.chunks2 = reinterpret_cast<const int4 *>(base + o_ch2);
+    d.bcs2 = reinterpret_cast<const int *>(base + o_bcs2);
+    d.w2 = reinterpret_cast<const float *>(base + o_w2);
+    d.tws2 = reinterpret_cast<const float2 *>(base + o_tws2);
     // the LDS the launch will ask for (same job shape as launch_featurize / launch_generic, same 160 KiB limit)
     if (d.n_fft == 1024) {
         feat_job_shape(d);
@@ -865,6 +946,13 @@ static int launch_featurize(const FeatDev &d0, const void *wav, int wav_dtype, i
     if (d0.n_fft != 1024) return launch_generic(d0, wav, wav_dtype, B, stride, valid_len, feat, stream);
     FeatDev d = d0;
     feat_job_shape(d);
+    if (v2_applies(d)) {
+        if (wav_dtype == KWS_WAV_F32)
+            return launch_v2_chp(d, static_cast<const float *>(wav), B, stride, valid_len, feat, static_cast<hipStream_t>(stream), "featurize_fft1024_f32");
+        if (wav_dtype == KWS_WAV_I16)
+            return launch_v2_chp(d, static_cast<const short *>(wav), B, stride, valid_len, feat, static_cast<hipStream_t>(stream), "featurize_fft1024_i16");
+        return fail(KWS_ERR_INVALID, "unknown wav dtype %d", wav_dtype);
+    }
     const size_t smem = feat_smem_bytes(d);
     if (smem > kMaxLdsBytes) return fail(KWS_ERR_UNSUPPORTED, "%d frames need %zu B of LDS (> 160 KiB)", d.n_frames, smem);
     hipStream_t s = static_cast<hipStream_t>(stream);

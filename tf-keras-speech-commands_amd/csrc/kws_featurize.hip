@@ -617,16 +617,44 @@ static bool v2_applies(const FeatDev &d)
 static size_t v2_smem_bytes(int chp)
 {
     constexpr int TB = 64 / kV2Bands;
-    return (size_t)kWaves * (kFftTile * 8 + 4 * (TB * 64 + 64 + 4)) + 4 * (size_t)(kV2Bands * kV2Coefs + 64 * chp) +
+    return (size_t)kV2Waves * (kFftTile * 8 + 4 * (TB * 64 + 64 + 4)) + 4 * (size_t)(kV2Bands * kV2Coefs + 64 * chp) +
            8 * (size_t)(7 * 64 + 7 * 8 + 4 * 64) + 4 * (size_t)round4(kV2Bands + 1);
 }
 template <typename WavT, int CHP>
 static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s,
                      const char *name)
 {
-    const long jobs = (long)B * d.jpc;
-    KWS_LAUNCH(name, (featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs>), dim3((unsigned)((jobs + kWaves - 1) / kWaves)), dim3(kThreads),
-               v2_smem_bytes(CHP), s, wav, stride, valid_len, B, d, feat);
+    // persistent grid: two 12-wave blocks per CU; frames per job chosen so that the jobs divide evenly over the grid's waves
+    static const int cus = [] {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) return p.multiProcessorCount;
+        (void)hipGetLastError();
+        return 256;
+    }();
+    static const bool attr = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem_bytes(CHP));
+        return true;
+    }();
+    (void)attr;
+    FeatDev dd = d;
+    const long waves = 2L * cus * kV2Waves;
+    {
+        // cost of a candidate = rounds of jobs per wave x (frames per job + the job's fixed part: one extra half frame of loads
+        // and a partly filled tail batch); candidates: the tail batch size and up, preferring divisors of the frame count
+        double best = -1.0;
+        for (int fpw = std::min(dd.n_frames, std::max(1, dd.tail_batch)); fpw <= dd.n_frames; ++fpw) {
+            const int jpc = (dd.n_frames + fpw - 1) / fpw;
+            const long jobs = (long)B * jpc, rounds = (jobs + waves - 1) / waves;
+            const double cost = (double)rounds * ((double)fpw + 1.25) + ((dd.n_frames % fpw) ? 0.5 : 0.0);
+            if (best < 0 || cost < best - 1e-9) { best = cost; dd.fpw = fpw; dd.jpc = jpc; }
+        }
+    }
+    const long jobs = (long)B * dd.jpc;
+    const unsigned grid = (unsigned)std::min<long>(2L * cus, (jobs + kV2Waves - 1) / kV2Waves);
+    KWS_LAUNCH(name, (featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs>), dim3(grid), dim3(kV2Waves * 64), v2_smem_bytes(CHP), s, wav,
+               stride, valid_len, B, dd, feat);
     KWS_LAUNCH_CHECK("featurize_fft1024_v2_kernel");
     return KWS_OK;
 }

@@ -21,8 +21,10 @@ namespace kws {
 // lane (hi = lane >> 3, lo = lane & 7) holds the FFT outputs ka + 64 r after pass 3
 __host__ __device__ inline int v2_ka(int lane) { return (lane >> 3) + 8 * (lane & 7); }
 
+constexpr int kV2Waves = 12;          // waves per block: 2 blocks per CU = 24 waves = 6 per SIMD (<= 80 VGPRs), the filter / twiddle tables twice per CU
+
 template <typename WavT, int CHP, int NF, int NO>
-__global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_v2_kernel(const WavT *__restrict__ wav, int64_t stride,
+__global__ __launch_bounds__(kV2Waves * 64, 6) void featurize_fft1024_v2_kernel(const WavT *__restrict__ wav, int64_t stride,
                                                                          const int32_t *__restrict__ valid_len, int B,
                                                                          FeatDev c, float *__restrict__ feat)
 {
@@ -32,8 +34,7 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_v2_kernel(const
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int job = (int)blockIdx.x * kWaves + wave;  // a job = c.fpw consecutive frames of one clip (no deltas in this kernel)
-    const int b = job / c.jpc;
+    constexpr int kWaves = kV2Waves, kThreads = kV2Waves * 64;
 
     float2 *s_fft = reinterpret_cast<float2 *>(smem) + wave * kFftTile;
     float *s_pw = reinterpret_cast<float *>(s_fft);                       // power spectrum aliases the FFT tile
@@ -56,8 +57,20 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_v2_kernel(const
     s_mel[lane] = 0.f;
     __syncthreads();
 
+    const int hi = lane >> 3, lo = lane & 7;
+    const int ka = hi + 8 * lo;                                            // this lane's FFT outputs are Z[ka + 64 r]
+    const int kp = (64 - ka) & 63;                                         // partner outputs Z[512 - k] live in the lane holding kp
+    const int partner = 4 * (((kp & 7) << 3) | (kp >> 3));                 // ds_bpermute byte address of that lane
+    const bool lane0 = lane == 0;
+    const int chunk_pack = c.chunks2[lane].y | (c.chunks2[lane].z << 16);  // first bin read (even) | slot of the partial sum
+
+    // Persistent waves: a JOB = c.fpw consecutive frames of one clip; the jobs of the batch are dealt round-robin to the
+    // grid's waves (the tables above are loaded once per block, not once per clip, and no block waits for a launch slot).
+    const int njobs = B * c.jpc;
+  for (int job = (int)blockIdx.x * kWaves + wave; job < njobs; job += (int)gridDim.x * kWaves) {
+    const int b = job / c.jpc;
     // clip geometry: keep the head, left-pad zeros (data_utils.py:77-80)
-    const int bc = b < B ? b : 0;                                          // idle waves read clip 0's geometry and do nothing
+    const int bc = b;
     int len = valid_len ? valid_len[bc] : (stride > c.max_samples ? c.max_samples : (int)stride);
     len = len < 0 ? 0 : len;
     if ((int64_t)len > stride) len = (int)stride;
@@ -66,15 +79,9 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_v2_kernel(const
     const WavT *src = wav + (int64_t)bc * stride;
     const bool vec_ok = ((pad & 1) == 0) && ((reinterpret_cast<uintptr_t>(src) & (2 * sizeof(WavT) - 1)) == 0);
 
-    const int hi = lane >> 3, lo = lane & 7;
-    const int ka = hi + 8 * lo;                                            // this lane's FFT outputs are Z[ka + 64 r]
-    const int kp = (64 - ka) & 63;                                         // partner outputs Z[512 - k] live in the lane holding kp
-    const int partner = 4 * (((kp & 7) << 3) | (kp >> 3));                 // ds_bpermute byte address of that lane
-    const bool lane0 = lane == 0;
-    const int chunk_pack = c.chunks2[lane].y | (c.chunks2[lane].z << 16);  // first bin read (even) | slot of the partial sum
     float *dst = feat + (int64_t)bc * c.n_frames * NO;
 
-    const int f_beg = b < B ? (job - b * c.jpc) * c.fpw : c.n_frames;
+    const int f_beg = (job - b * c.jpc) * c.fpw;
     const int f_end = f_beg + c.fpw < c.n_frames ? f_beg + c.fpw : c.n_frames;
 
     float2 xl[4], xh[4];                // lower / upper half of the next frame to transform
@@ -214,6 +221,7 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_v2_kernel(const
         qi = 0;
         wave_sync();
     }
+  }
 }
 
 }  // namespace kws

@@ -273,7 +273,8 @@ def extra_workloads(torch, pr, feat_fn, reps):
     spec = ModelSpec("simple_gru", N_CLASSES, pr.n_features, pr.feature_size)
     dm = DeviceModel(spec)
     dm.set_weights(init_weights(spec, seed=0))
-    pipe = FeaturePipeline(feat_fn, B, pr.n_features, pr.feature_size)
+    from kws_amd.featurizer import Featurizer
+    pipe = FeaturePipeline(Featurizer(pr), B, pr.n_features, pr.feature_size)
     ev = torch.cuda.Event()
 
     def gru_steps(n, k0):
@@ -370,7 +371,9 @@ def main():
         comm = KwsComm.single()
     split = dm.grad_split
     from kws_amd.pipeline import FeaturePipeline
-    pipe = FeaturePipeline(feat_fn, B, pr.n_features, pr.feature_size)
+    # the pipeline's featurizer shares the chip with the train step (half of each CU's LDS, FeaturePipeline sets it), so it is
+    # its own object: feat_fn keeps the whole chip for the stand-alone workloads under `extra`
+    pipe = FeaturePipeline(Featurizer(pr), B, pr.n_features, pr.feature_size)
     step_no = [0]
     overlap_ev = torch.cuda.Event()
     bucket_ev = torch.cuda.Event() if comm is not None else None

@@ -56,7 +56,7 @@ struct FeatDev {
     const int *bwidth;   // [n_filt] span length
     const float *bw;     // [n_filt][n_bins] dense bank rows (float)
     // second-generation kernel (kws_featurize_v2.h): chunks placed on even bins, split twiddles in the kernel's lane order
-    int chp2;
+    int chp2, blocks_per_cu;
     const int4 *chunks2; // [64 lanes] {band, first bin read (even), chunk id, 0}
     const int *bcs2;     // [n_filt+1]
     const float *w2;     // [64 lanes][chp2]
@@ -73,6 +73,7 @@ struct kws_featurizer {
     kws::FeatDev dev;
     void *dmem;               // one device allocation holding every table
     size_t smem_bytes;
+    int blocks_per_cu = 2;    // persistent blocks per CU of the tuned kernel (kws_featurizer_set_cu_share)
 };
 
 namespace kws {
@@ -639,7 +640,8 @@ static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, c
     }();
     (void)attr;
     FeatDev dd = d;
-    const long waves = 2L * cus * kV2Waves;
+    const int bpc = d.blocks_per_cu == 1 ? 1 : 2;
+    const long waves = (long)bpc * cus * kV2Waves;
     {
         // cost of a candidate = rounds of jobs per wave x (frames per job + the job's fixed part: one extra half frame of loads
         // and a partly filled tail batch); candidates: the tail batch size and up, preferring divisors of the frame count
@@ -652,7 +654,7 @@ static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, c
         }
     }
     const long jobs = (long)B * dd.jpc;
-    const unsigned grid = (unsigned)std::min<long>(2L * cus, (jobs + kV2Waves - 1) / kV2Waves);
+    const unsigned grid = (unsigned)std::min<long>((long)bpc * cus, (jobs + kV2Waves - 1) / kV2Waves);
     KWS_LAUNCH(name, (featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs>), dim3(grid), dim3(kV2Waves * 64), v2_smem_bytes(CHP), s, wav,
                stride, valid_len, B, dd, feat);
     KWS_LAUNCH_CHECK("featurize_fft1024_v2_kernel");
@@ -1012,7 +1014,17 @@ int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int6
     if (B < 0 || stride < 0) return fail(KWS_ERR_INVALID, "negative batch or stride");
     if (B == 0) return KWS_OK;
     if (!valid_len && stride < 1) return fail(KWS_ERR_INVALID, "stride must be >= 1 when valid_len is NULL");
-    return launch_featurize(f->dev, wav, wav_dtype, B, stride, valid_len, feat, stream);
+    FeatDev d = f->dev;
+    d.blocks_per_cu = f->blocks_per_cu;
+    return launch_featurize(d, wav, wav_dtype, B, stride, valid_len, feat, stream);
+}
+
+int kws_featurizer_set_cu_share(kws_featurizer *f, int blocks_per_cu)
+{
+    if (!f) return fail(KWS_ERR_INVALID, "null argument");
+    if (blocks_per_cu != 1 && blocks_per_cu != 2) return fail(KWS_ERR_INVALID, "blocks_per_cu must be 1 or 2");
+    f->blocks_per_cu = blocks_per_cu;
+    return KWS_OK;
 }
 
 int kws_featurizer_occupancy(const kws_featurizer *f, int *blocks_per_cu, size_t *lds_bytes)
@@ -1047,6 +1059,7 @@ int kws_featurize_raw(kws_featurizer *f, const void *wav, int wav_dtype, int B, 
     d.max_samples = n_samples;
     d.use_delta = 0;
     d.feature_size = d.n_out;
+    d.blocks_per_cu = f->blocks_per_cu;
     return launch_featurize(d, wav, wav_dtype, B, stride, nullptr, feat, stream);
 }
 

@@ -56,6 +56,11 @@ class Featurizer(object):
         except Exception:
             pass
 
+    def set_cu_share(self, blocks_per_cu):
+        """2 (default): a launch may fill every CU's LDS (fastest alone); 1: half of it, leaving room for kernels of other
+        streams (featurizing beside a train step: kws_amd.pipeline.FeaturePipeline sets this)."""
+        _l.check(self._L.kws_featurizer_set_cu_share(self._h, int(blocks_per_cu)))
+
     def occupancy(self):
         """(resident clips per compute unit, LDS bytes per clip) the HIP runtime reports for this featurizer's kernel."""
         nb, lds = ctypes.c_int(0), ctypes.c_size_t(0)

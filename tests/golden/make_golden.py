@@ -73,7 +73,7 @@ def main():
         return bf.bfcc_spec(audio, pr.sample_rate, pr.window_samples, pr.hop_samples, fft_size=pr.n_fft,
                             num_filt=pr.n_filt, num_coeffs=pr.n_mfcc)
 
-    names = ["right_1", "left_1", "up_1", "down_1"]
+    names = ["right_1", "left_1", "up_1", "down_1", "right_2", "left_2", "up_2", "down_2"]   # every clip under example/
     for n in names:
         pcm = read_wav_i16(os.path.join(REF, "example", n + ".wav"))
         assert len(pcm) == 16000

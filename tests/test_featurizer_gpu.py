@@ -10,7 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 ATOL = 2e-4
-NAMES = ["right_1", "left_1", "up_1", "down_1"]
+NAMES = ["right_1", "left_1", "up_1", "down_1", "right_2", "left_2", "up_2", "down_2"]   # all eight clips of the reference's example/
 
 
 @pytest.fixture(scope="module")

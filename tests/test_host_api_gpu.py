@@ -215,3 +215,43 @@ def test_inference_session_end_to_end_pcm16(torch, model_type, fp16):
     top2 = np.sort(want, axis=-1)[:, -2:]
     clear = (top2[:, 1] - top2[:, 0]) > 2e-3
     np.testing.assert_array_equal(ag.cpu().numpy()[clear], want.argmax(-1)[clear])
+
+
+def test_eight_example_clips_argmax_agreement(torch, golden):
+    """SURVEY 8(d) substitute for the unavailable Speech Commands v2 top-1: train on a synthetic separable task through the host
+    API, then run the reference's eight example clips (example/*.wav, PCM in the golden file) through featurize + predict on
+    the GPU and through the CPU restatement with the SAME trained weights: class-index argmax identical on all eight,
+    probabilities within 1e-3 (north star), for simple_cnn and simple_gru."""
+    from classifier.loss import SparseCategoricalCrossEntropy
+    from classifier.model import KWSModel
+    from common.model_utils import get_optimizer
+    from oracle import featurizer_oracle as fo
+    from oracle import model_oracle as mo
+    names = ["right_1", "left_1", "up_1", "down_1", "right_2", "left_2", "up_2", "down_2"]
+    pcm = np.stack([golden["pcm_" + n] for n in names])
+    assert pcm.shape == (8, 16000) and pcm.dtype == np.int16
+    feats = fo.featurize_batch(pcm.astype(np.float32) / 32768.0).astype(np.float64)      # data_utils.py:21 scaling
+    C = 5
+    rng = np.random.default_rng(17)
+    for model_type in ("simple_cnn", "simple_gru"):
+        # separable task built AROUND the real clips' features, so that the trained net gives them confident, distinct answers
+        lab = np.array([1, 2, 3, 4, 1, 2, 3, 4])
+        xs = np.concatenate([feats[rng.integers(0, 8, 256)] for _ in range(1)])
+        idx = rng.integers(0, 8, 512)
+        x = (feats[idx] + 0.3 * rng.standard_normal((512, 30, 20))).astype(np.float32)
+        y = lab[idx]
+        bg = (0.5 * rng.standard_normal((128, 30, 20)) - 20.0).astype(np.float32)            # class 0: quiet background
+        x, y = np.concatenate([x, bg]), np.concatenate([y, np.zeros(128, np.int64)])
+        m = KWSModel(model_type, C, seed=5)
+        m.compile(optimizer=get_optimizer("adam", 2e-3, decay_type=None), loss=SparseCategoricalCrossEntropy(), metrics=["accuracy"])
+        xin = x[..., None] if model_type == "simple_cnn" else x
+        h = m.fit(xin, y, batch_size=128, epochs=12, verbose=0)
+        assert h.history["accuracy"][-1] > 0.9, (model_type, h.history["accuracy"])
+        got = m.predict(pcm)                                  # raw PCM16 audio: featurized on the GPU in front of the network
+        om = mo.Model(model_type, C)
+        om.set_weights([w.astype(np.float64) for w in m.get_weights()])
+        want = om.predict(feats)
+        np.testing.assert_array_equal(got.argmax(-1), want.argmax(-1))
+        np.testing.assert_allclose(got, want, atol=1e-3, rtol=0)
+        assert (want.argmax(-1) == lab).sum() >= 6, (model_type, want.argmax(-1))        # and the answers are the trained ones
+        del xs

@@ -342,7 +342,9 @@ def test_lite_multi_step_training_tracks_oracle(torch):
     from oracle import model_oracle as mo
     C, B = 5, 64
     om, dm = build("simple_cnn_lite", C, seed=6, perturb=False)
+    dm.set_deterministic(True)
     rng = np.random.default_rng(31)
+    worst = 0.0
     protos = rng.standard_normal((C, 30, 20)) * 2
     opt = mo.Adam(1e-3)   # the reference's default learning rate (train.py:128)
     for it in range(8):
@@ -354,8 +356,11 @@ def test_lite_multi_step_training_tracks_oracle(torch):
         # Stage 1 of the lite model (1-channel depthwise -> pointwise -> BatchNorm) is scale invariant, so some depthwise
         # gradient components are ~0; Adam's first steps move those weights by +-lr on the SIGN of fp32 noise (measured:
         # one weight differs by exactly 2*lr after step 0 while every gradient matches to 3e-4).  simple_cnn, which has no
-        # such direction, tracks the oracle to 1e-7 with the same code.  Hence 5e-3 here instead of 1e-3.
-        assert abs(float(dm.stats[0].item()) / B - lo) < 5e-3, it
+        # such direction, tracks the oracle to 1e-7 with the same code.  Hence 3e-3 here (measured 2.0e-3) instead of 1e-3; every
+        # single step from a synchronised state is held to 1e-4 by test_resynced_steps_match_oracle_elementwise.
+        worst = max(worst, abs(float(dm.stats[0].item()) / B - lo))
+        assert abs(float(dm.stats[0].item()) / B - lo) < 3e-3, it
+    print("lite 8-step trajectory: max |loss - oracle| = %.2e" % worst)
 
 
 def test_cnn_full_batch_4096_grids(torch):
@@ -735,3 +740,136 @@ def test_oversized_dense_map_is_reported_not_ignored(torch):
     with pytest.raises(L.KwsError):
         dm.train_fwd_bwd(x, y)
     torch.cuda.synchronize()
+
+
+def _flat_trainable(dm, arrays):
+    """Keras-ordered trainable arrays -> the device's flat float32 layout (offsets are multiples of 4 floats, gaps zero)"""
+    flat = np.zeros((dm.params.numel(),), np.float32)
+    it = iter(arrays)
+    for t in dm.spec.tensors:
+        if t["trainable"]:
+            flat[t["offset"]:t["offset"] + t["size"]] = np.asarray(next(it), np.float32).reshape(-1)
+    return flat
+
+
+@pytest.mark.parametrize("model_type", ["simple_cnn", "simple_cnn_lite"])
+def test_resynced_steps_match_oracle_elementwise(torch, model_type):
+    """Every optimizer step checked ELEMENTWISE.  Before each step the device model takes the oracle's weights and Adam moments
+    (so differences cannot accumulate), runs one step in the deterministic gradient mode and is compared with the float64
+    oracle's step from the same state: loss within 1e-4, BatchNormalization statistics within 2e-5, and every weight within
+    5 % of the learning rate -- except entries whose update is ill-conditioned, which are COUNTED, reported and bounded:
+      * Adam divides by sqrt(v): where the oracle gradient entry is below 1e-3 of its tensor's largest, float32 rounding of
+        the gradient moves the update by a visible fraction of lr (at step 1 the update is lr * sign(g) whatever |g|);
+      * a max-pool arg-max / ReLU6 gate that is a tie within float32 rounding routes one gradient element differently
+        (DESIGN.md section 4): a handful of entries of the layers below it.
+    A wrong gradient, mask, statistic or optimizer constant moves ALL entries of a tensor and fails the 5 % bound outright."""
+    from oracle import model_oracle as mo
+    C, B, lr = 5, 64, 1e-3
+    om, dm = build(model_type, C, seed=8, perturb=False)
+    dm.set_deterministic(True)
+    rng = np.random.default_rng(61)
+    protos = rng.standard_normal((C, 30, 20)) * 2
+    opt = mo.Adam(lr)
+    trainable = [t for t in dm.spec.tensors if t["trainable"]]
+    total_bad = total_ill = total = 0
+    for it in range(6):
+        y = rng.integers(0, C, B)
+        x = (protos[y] + 0.5 * rng.standard_normal((B, 30, 20))).astype(np.float32)
+        seed = 4000 + it
+        # device state <- oracle state
+        dm.set_weights(om.get_weights())
+        if opt.m is not None:
+            dm.adam_m.copy_(torch.from_numpy(_flat_trainable(dm, opt.m)))
+            dm.adam_v.copy_(torch.from_numpy(_flat_trainable(dm, opt.v)))
+        dm.step_count = opt.t
+        w_before = [w.copy() for w in om.trainable_list()]
+        loss_o, _ = mo.train_step(om, opt, x.astype(np.float64), y, dropout_seed=seed)
+        g_o = [g.copy() for g in om.grad_list()]
+        dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(), dropout_seed=seed)
+        dm.adam_step(lr)
+        assert abs(float(dm.stats[0].item()) / B - loss_o) < 1e-4, it
+        got = dm.get_weights()
+        for w_d, w_o, (li, n, t) in zip(got, om.get_weights(), om.weight_list()):
+            if not t:
+                np.testing.assert_allclose(w_d, w_o, rtol=2e-5, atol=1e-6, err_msg="step %d %s" % (it, n))
+        got_tr = [w for w, (_, _, t) in zip(got, om.weight_list()) if t]
+        for w_d, w_o, w0, g, tinfo in zip(got_tr, om.trainable_list(), w_before, g_o, trainable):
+            d = np.abs(w_d - w_o) / lr
+            assert np.all(np.abs(w_d - w0) <= 1.001 * lr * 3.2), tinfo["name"]       # an Adam step never exceeds ~lr/(1-b1) early on
+            gmax = np.abs(g).max()
+            # (a bias in front of BatchNormalization has an exactly-zero gradient, ~1e-16 in the oracle: absolute floor 1e-6)
+            well = np.abs(g) > max(1e-3 * gmax, 1e-6)
+            bad = well & (d > 0.05)
+            total_bad += int(bad.sum())
+            total_ill += int((~well).sum())
+            total += d.size
+            assert np.all(d[~well] <= 2.0 + 1e-3), (it, tinfo["name"], float(d.max()))   # sign flip of a ~0 gradient: at most 2 lr
+            # routed-gradient ties: a handful of well-conditioned entries of the layers under a pool / ReLU6 gate
+            assert bad.sum() <= max(2, 0.01 * d.size), (it, tinfo["name"], int(bad.sum()), float(d[bad].max()) if bad.any() else 0.0)
+    print("%s: %d of %d weight entries ill-conditioned (|g| < max(1e-3 max|g|, 1e-6)), %d well-conditioned entries beyond 5 %% of lr (ties)" %
+          (model_type, total_ill, total, total_bad))
+    assert total_bad <= 0.002 * total
+
+
+def test_gru_train_step_at_bench_batch_2048(torch):
+    """BASELINE configs[2] at its full size: simple_gru, B = 2048, 36 classes -- the launch grids of gru_fwd / gru_bwd at the
+    bench batch.  The numpy oracle is fast enough for this model to check the WHOLE batch: loss 1e-4, probabilities 1e-4,
+    every gradient tensor within 1e-3 of its largest entry (float32 sums over 2048 x 30 steps, float atomics); plus batch
+    invariance of the per-clip results (a clip's probabilities do not depend on which batch it rides in)."""
+    from oracle import model_oracle as mo
+    C, B = 36, 2048
+    om, dm = build("simple_gru", C)
+    x = features(B, 71)
+    y = np.random.default_rng(72).integers(0, C, B).astype(np.int32)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    loss, acc, p = mo.train_forward_backward(om, x.astype(np.float64), y, dropout_seed=77)
+    probs = dm.train_fwd_bwd(xt, yt, dropout_seed=77, want_probs=True)
+    np.testing.assert_allclose(probs.cpu().numpy(), p, atol=1e-4, rtol=0)
+    assert abs(float(dm.stats[0].item()) / B - loss) < 1e-4 and float(dm.stats[1].item()) == round(acc * B)
+    for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
+        assert rel_err(g, want) < 1e-3, (li, n, rel_err(g, want))
+    sub, _ = dm.forward(xt[:100].contiguous())
+    full, _ = dm.forward(xt)
+    assert torch.equal(sub, full[:100])
+
+
+def test_lite_fp16_graph_at_bench_batch_16384(torch):
+    """BASELINE configs[4] at its full size: hipGraph-captured featurize + simple_cnn_lite fp16 forward, B = 16 384 PCM16 clips.
+    Properties that hold exactly: replay determinism, graph == eager, batch invariance (the first 4096 clips give the same
+    bits as a 4096-clip session); against the float64 oracle on a 384-clip sample: probabilities within 1e-3, argmax exact
+    where the oracle's two best classes are more than 2e-3 apart."""
+    from classifier.params import pr
+    from kws_amd.featurizer import Featurizer
+    from kws_amd.inference import InferenceSession
+    from oracle import featurizer_oracle as fo
+    B, C = 16384, 36
+    om, dm = build("simple_cnn_lite", C)
+    feat = Featurizer(pr)
+    rng = np.random.default_rng(81)
+    pcm = np.clip(3000.0 * rng.standard_normal((B, 16000), dtype=np.float32), -32768, 32767).astype(np.int16)
+    lead = rng.integers(0, 8000, B)
+    for b in np.nonzero(rng.uniform(size=B) < 0.25)[0]:
+        pcm[b, :lead[b]] = 0                                  # leading silence: the log-floor frames of short recordings
+    big = InferenceSession(dm, feat, B, wav_dtype=torch.int16, use_graph=True, fp16=True)
+    big.wav.copy_(torch.from_numpy(pcm))
+    p1, a1 = big.run()
+    p1, a1 = p1.clone(), a1.clone()
+    p2, a2 = big.run()
+    assert torch.equal(p1, p2) and torch.equal(a1, a2)
+    eager = InferenceSession(dm, feat, B, wav_dtype=torch.int16, use_graph=False, fp16=True)
+    eager.wav.copy_(big.wav)
+    pe, ae = eager.run()
+    assert torch.equal(pe, p1) and torch.equal(ae, a1)
+    small = InferenceSession(dm, feat, 4096, wav_dtype=torch.int16, use_graph=True, fp16=True)
+    small.wav.copy_(big.wav[:4096])
+    ps, as_ = small.run()
+    assert torch.equal(ps, p1[:4096]) and torch.equal(as_, a1[:4096])
+    sel = rng.choice(B, 384, replace=False)
+    x = fo.featurize_batch(pcm[sel].astype(np.float32) / 32768.0)
+    want = om.predict(x.reshape(len(sel), pr.n_features, pr.feature_size).astype(np.float64))
+    got = p1[torch.from_numpy(sel).cuda()].cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=1e-3, rtol=0)
+    top2 = np.sort(want, axis=-1)[:, -2:]
+    clear = (top2[:, 1] - top2[:, 0]) > 2e-3
+    np.testing.assert_array_equal(a1[torch.from_numpy(sel).cuda()].cpu().numpy()[clear], want.argmax(-1)[clear])
+    assert abs(float(p1.sum(-1).mean()) - 1.0) < 1e-5

@@ -8,7 +8,7 @@ import pytest
 
 from oracle import featurizer_oracle as fo
 
-NAMES = ["right_1", "left_1", "up_1", "down_1"]
+NAMES = ["right_1", "left_1", "up_1", "down_1", "right_2", "left_2", "up_2", "down_2"]   # all eight clips of the reference's example/
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 

@@ -62,6 +62,8 @@ def kernel_models(B, C):
     a = [15 * 10 * 16, 7 * 5 * 32, 4 * 3 * 64, 256]                    # activations per clip
     m = {}
     m["featurize_fft1024_f32"] = ("hbm", B * FEAT_BYTES_PER_CLIP)
+    m["l1_moments_kernel"] = ("hbm", B * 600.0 * f)
+    m["l1m_bwd_onepass_kernel"] = ("hbm", B * (600 + a[0]) * f)
     # layer 1 is recomputed from the feature map (kws_layer1.h): bytes = features (+ a1 / da1), never a z1-sized tensor
     for k, v in (("stats", 600.0), ("act_pool", 600 + a[0]), ("bwd_reduce", 600 + a[0]), ("bwd_wgrad", 600 + a[0])):
         m["l1_%s_kernel" % k] = m["l1m_%s_kernel" % k] = ("hbm", B * v * f)
@@ -373,7 +375,7 @@ def main():
     from kws_amd.pipeline import FeaturePipeline
     # the pipeline's featurizer shares the chip with the train step (half of each CU's LDS, FeaturePipeline sets it), so it is
     # its own object: feat_fn keeps the whole chip for the stand-alone workloads under `extra`
-    pipe = FeaturePipeline(Featurizer(pr), B, pr.n_features, pr.feature_size)
+    pipe = FeaturePipeline(Featurizer(pr), B, pr.n_features, pr.feature_size, moments=True)   # + kws_feature_moments behind the featurizer
     step_no = [0]
     overlap_ev = torch.cuda.Event()
     bucket_ev = torch.cuda.Event() if comm is not None else None
@@ -390,11 +392,11 @@ def main():
         pipe.submit(wav)
         for i in range(n):
             step_no[0] += 1
-            feat = pipe.take()
+            feat, mom = pipe.take()
             # next batch's features on the side stream, started behind this step's last forward convolution: the library
             # records overlap_ev there and calls back, so the featurizer launch also sits at that point in HOST order
             dm.train_fwd_bwd(feat, labels, dropout_seed=step_no[0], grad_scale=1.0 / world, overlap_event=overlap_ev,
-                             overlap_callback=submit_next if i + 1 < n else None, bucket_event=bucket_ev)
+                             overlap_callback=submit_next if i + 1 < n else None, bucket_event=bucket_ev, feat_moments=mom)
             # no pipe.release() here: the featurizer that rewrites this step's feature buffer (batch k+2) is ordered behind the NEXT
             # step's overlap event on this stream, i.e. behind every kernel of this step
             if comm is not None:
@@ -552,7 +554,7 @@ def main():
                           "matrix_precision": "conv2/conv3/conv4/dense products as three-way bf16 splits on the bf16 matrix cores "
                                               "with fp32 accumulation (fp32-level error, kws_model_set_precision); conv1, conv3 "
                                               "data gradient, dense weight gradient and everything else fp32; extra.fp32_mfma_step is the all-fp32 number",
-                          "input_pipeline": "features of batch k+1 computed on a side stream during step k, started behind the last forward convolution (kws_train_args.overlap_event; all K featurizations inside the timed region)",
+                          "input_pipeline": "features of batch k+1 (and their second moments for layer 1, kws_feature_moments) computed on a side stream during step k, started behind the last forward convolution (kws_train_args.overlap_event; all K featurizations inside the timed region)",
                           "gradient_exchange": ("kws_allreduce_grads (RCCL behind the C ABI): early bucket grads[%d:] on the communicator's stream behind the library's bucket event, "
                                                 "late bucket + BN moving statistics grouped behind the backward pass, Adam waits for both" % split) if comm is not None else "none (one rank)",
                           "allreduce_us": allreduce_us,

@@ -207,8 +207,25 @@ typedef struct kws_train_args {
                                    puts that launch at the same place in HOST order, so the overlap does not depend on how far
                                    the host runs ahead of the device (under a tracing profiler it does not run ahead at all) */
     void *overlap_user;
+    const double *feat_moments; /* NULL or the KWS_FEATURE_MOMENTS doubles kws_feature_moments() wrote for `feat` (same B): simple_cnn
+                                   derives the batch statistics of its first BatchNormalization and the closed forms of its first
+                                   layer's gradients from them instead of computing them at the head of the step, so an input
+                                   pipeline can prepare them on its own stream right behind the featurizer.  Ignored by the
+                                   other model kinds and at geometries kws_feature_moments() does not cover.             */
 } kws_train_args;
 int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream);
+
+/* Second moments of a feature batch as seen by a 3x3 'same' convolution with one input channel (the first layer of
+ * classifier/models/cnn.py:27): Q[t][t'] = sum over clips and pixels of a_t a_t', a_t = the feature at tap t of the pixel's
+ * 3x3 patch (zero outside the map) for t < 9 and a_9 = 1; row-major 10 x 10 doubles (Q[t][9] = tap sums, Q[9][9] = B*H*W).
+ * They depend on the features only, so they can be computed where the features are produced (kws_train_args.feat_moments).
+ * ws: kws_feature_moments_workspace_bytes() bytes of 256-byte aligned device scratch.  Deterministic (fixed summation order).
+ * KWS_ERR_UNSUPPORTED outside the geometries of the wave-per-clip kernels (H, W even, (H+2)(W+2) <= 768, H*W/4 <= 160): pass
+ * feat_moments = NULL there. */
+#define KWS_FEATURE_MOMENTS 100
+int64_t kws_feature_moments_workspace_bytes(int B);
+int kws_feature_moments(const float *feat, int B, int n_features, int feature_size, double *moments, void *ws, size_t ws_bytes,
+                        void *stream);
 /* Arithmetic of the GEMM-shaped layers with 32 or more reduced channels (simple_cnn: conv3, conv4, dense).
  *   KWS_MATRIX_BF16X6 (default): every fp32 operand is carried as h + m + l in bf16 (24 bits) and a product is the six
  *                      leading partial products on the bf16 matrix cores with fp32 accumulation: fp32-level error at

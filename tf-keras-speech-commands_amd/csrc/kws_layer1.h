@@ -362,42 +362,6 @@ __device__ __forceinline__ void l1m_reduce_store(double s0, double s1, double *_
     }
 }
 
-__device__ __forceinline__ void l1m_stats_body(const float *__restrict__ feat, const float *__restrict__ wk, int B, int H, int W,
-                                               int clips_per_wave, double *__restrict__ partial)
-{
-    extern __shared__ float l1smem[];
-    const int lq = (threadIdx.x & 63) >> 4;
-    L1Mma t;
-    t.init(wk, H, W, l1smem);
-    long first;
-    int count;
-    l1m_clips(B, clips_per_wave, first, count);
-    double s = 0.0, ss = 0.0;
-    if (count > 0) t.fetch(feat, first);
-    for (int i = 0; i < count; ++i) {
-        t.store();
-        if (i + 1 < count) t.fetch(feat, first + i + 1);
-        float fs = 0.f, fss = 0.f;
-        t.first_tile();
-        for (int tile = 0; tile < t.ntile; ++tile, t.next_tile()) {
-            const f32x4 z = t.z();
-            if (4 * tile + lq < t.nwin) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { fs += z[r]; fss = fmaf(z[r], z[r], fss); }
-            }
-        }
-        s += (double)fs;
-        ss += (double)fss;
-    }
-    l1m_reduce_store(s, ss, partial);
-}
-
-__global__ __launch_bounds__(256) void l1m_stats_kernel(const float *__restrict__ feat, const float *__restrict__ wk, int B, int H,
-                                                         int W, int clips_per_wave, double *__restrict__ partial)
-{
-    l1m_stats_body(feat, wk, B, H, W, clips_per_wave, partial);
-}
-
 __global__ __launch_bounds__(256) void l1m_act_pool_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
                                                             const float *__restrict__ scale, const float *__restrict__ shift,
                                                             float *__restrict__ a1, int B, int H, int W, int clips_per_wave)
@@ -422,124 +386,6 @@ __global__ __launch_bounds__(256) void l1m_act_pool_kernel(const float *__restri
             const int win = 4 * tile + lq;
             if (win < t.nwin) out[win * 16] = relu6f(fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
         }
-    }
-}
-
-// (256, 4): four blocks (one wave per clip each) per CU keep all 1024 blocks of a B = 4096 step resident at once
-__global__ __launch_bounds__(256, 4) void l1m_bwd_reduce_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
-                                                              const float *__restrict__ da1, BnCoef k, int B, int H, int W,
-                                                              int clips_per_wave, double *__restrict__ partial)
-{
-    extern __shared__ float l1smem[];
-    const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
-    L1Mma t;
-    t.init(wk, H, W, l1smem);
-    long first;
-    int count;
-    l1m_clips(B, clips_per_wave, first, count);
-    const float sc = k.scale[li], sh = k.shift[li], mean = k.mean[li], inv = k.inv[li];
-    double s = 0.0, sx = 0.0;
-    if (count > 0) t.fetch(feat, first);
-    for (int i = 0; i < count; ++i) {
-        // da1 in groups of kL1Group tiles, fetched one group ahead (all of a group's loads are in flight together)
-        const float *dsrc = da1 + (first + i) * t.nwin * 16 + li;
-        float dcur[kL1Group], dnxt[kL1Group];
-        auto fetch_da = [&](int t0, float (&dv)[kL1Group]) {
-#pragma unroll
-            for (int j = 0; j < kL1Group; ++j) dv[j] = 4 * (t0 + j) + lq < t.nwin ? dsrc[(4 * (t0 + j) + lq) * 16] : 0.f;
-        };
-        fetch_da(0, dnxt);
-        t.store();
-        if (i + 1 < count) t.fetch(feat, first + i + 1);
-        float fs = 0.f, fsx = 0.f;
-        t.first_tile();
-        for (int t0 = 0; t0 < t.ntile; t0 += kL1Group) {
-#pragma unroll
-            for (int j = 0; j < kL1Group; ++j) dcur[j] = dnxt[j];
-            if (t0 + kL1Group < t.ntile) fetch_da(t0 + kL1Group, dnxt);
-#pragma unroll
-            for (int j = 0; j < kL1Group; ++j) {
-                const int tile = t0 + j;
-                if (tile < t.ntile) {
-                    const f32x4 z = t.z();
-                    t.next_tile();
-                    int arg;
-                    float g;
-                    l1m_route(z, sc, sh, dcur[j], arg, g);
-                    const float za = arg == 0 ? z[0] : arg == 1 ? z[1] : arg == 2 ? z[2] : z[3];
-                    fs += g;
-                    fsx = fmaf(g, (za - mean) * inv, fsx);
-                }
-            }
-        }
-        s += (double)fs;
-        sx += (double)fsx;
-    }
-    l1m_reduce_store(s, sx, partial);
-}
-
-__global__ __launch_bounds__(256, 4) void l1m_bwd_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
-                                                             const float *__restrict__ da1, BnCoef k, const float *__restrict__ gamma,
-                                                             float *__restrict__ dw, int B, int H, int W, int clips_per_wave)
-{
-    extern __shared__ float l1smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
-    L1Mma t;
-    t.init(wk, H, W, l1smem);
-    long first;
-    int count;
-    l1m_clips(B, clips_per_wave, first, count);
-    const float sc = k.scale[li], sh = k.shift[li], mean = k.mean[li], inv = k.inv[li];
-    const float k1 = gamma[li] * inv, k2 = k.k2[li], k3 = k.k3[li];
-    // B side of the weight-gradient MFMA: this lane supplies x at tap li (< 9) of the element's pixel in window 4 tile + lq
-    const int tap = li < 9 ? li : 8, boff = (tap / 3) * t.WP + tap % 3;
-    const float bmask = li < 9 ? 1.f : 0.f;
-    f32x4 accw = {0.f, 0.f, 0.f, 0.f};                 // dW[c = 4 lq + r][tap = li]
-    if (count > 0) t.fetch(feat, first);
-    for (int i = 0; i < count; ++i) {
-        const float *dsrc = da1 + (first + i) * t.nwin * 16 + li;
-        float dcur[kL1Group], dnxt[kL1Group];
-        auto fetch_da = [&](int t0, float (&dv)[kL1Group]) {
-#pragma unroll
-            for (int j = 0; j < kL1Group; ++j) dv[j] = 4 * (t0 + j) + lq < t.nwin ? dsrc[(4 * (t0 + j) + lq) * 16] : 0.f;
-        };
-        fetch_da(0, dnxt);
-        t.store();
-        if (i + 1 < count) t.fetch(feat, first + i + 1);
-        t.first_tile();
-        for (int t0 = 0; t0 < t.ntile; t0 += kL1Group) {
-#pragma unroll
-            for (int j = 0; j < kL1Group; ++j) dcur[j] = dnxt[j];
-            if (t0 + kL1Group < t.ntile) fetch_da(t0 + kL1Group, dnxt);
-#pragma unroll
-            for (int j = 0; j < kL1Group; ++j) {
-                const int tile = t0 + j;
-                if (tile < t.ntile) {
-                    const int win = 4 * tile + lq;
-                    const bool ok = win < t.nwin;
-                    const f32x4 z = t.z();
-                    int arg;
-                    float g;
-                    l1m_route(z, sc, sh, dcur[j], arg, g);
-                    const float *xb = t.xs + t.d_window_offset(ok) + boff;
-                    t.next_tile();
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float dz = k1 * ((r == arg ? g : 0.f) - k2 - (z[r] - mean) * inv * k3);
-                        dz = ok ? dz : 0.f;
-                        accw = mfma16(dz, xb[(r >> 1) * t.WP + (r & 1)] * bmask, accw);
-                    }
-                }
-            }
-        }
-    }
-    __shared__ float shw[4][16][17];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) shw[wave][4 * lq + r][li] = accw[r];
-    __syncthreads();
-    if (threadIdx.x < 9 * 16) {
-        const int tp = threadIdx.x / 16, c = threadIdx.x % 16;
-        atomicAdd(dw + tp * 16 + c, (shw[0][c][tp] + shw[1][c][tp]) + (shw[2][c][tp] + shw[3][c][tp]));
     }
 }
 

@@ -13,6 +13,7 @@
 #include "kws_conv.h"
 #include "kws_layers.h"
 #include "kws_layer1.h"
+#include "kws_layer1_moments.h"
 #include "kws_lite.h"
 #include "kws_lite_f16.h"
 
@@ -48,6 +49,7 @@ struct CnnWs {
     __bf16 *wsp[3][6];  // simple_cnn: bf16 h/m/l planes of conv3, conv4 and dense weights (original order x3, transposed x3; kws_conv.h)
     __bf16 *dzp[3];     // simple_cnn training: h/m/l planes of dz4 (written by BN4's backward, read by conv4's data / weight gradients)
     double *partial;    // [kMaxStatBlocks][2][256]
+    double *moments;    // Q[10][10] of the feature map (kws_layer1_moments.h) when the caller did not supply it
     size_t bytes;
 };
 
@@ -77,6 +79,7 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
             for (int q = 0; q < 6; ++q) w.wsp[t][q] = reinterpret_cast<__bf16 *>(take(lite ? 0 : (wn[t] + 1) / 2));
     }
     w.partial = reinterpret_cast<double *>(take((size_t)kMaxStatBlocks * 9 * 64 * 2));   // [9*64 or 2*C rows][kStatStride] doubles
+    w.moments = reinterpret_cast<double *>(take(2 * kMomCount));
     if (training) {
         w.dlogits = take((size_t)B * m->C);
         w.dd1 = take((size_t)B * 128);
@@ -321,28 +324,18 @@ ConvGeom geom3x3(int B, int H, int W, int stride)
     return g;
 }
 
-// First kernel of a training forward pass in split precision: the layer-1 statistics blocks, and behind them in the SAME grid
-// 48 blocks that split the conv3 / conv4 / dense weights into their bf16 planes and 16 that clear the gradient buffer.  Both
-// jobs used to run on the side stream behind an event and were joined before conv3: two events on the main chain (6-8 us
-// each) for 12 us of work that hides under the statistics pass.
+// Training forward pass in split precision: 48 extra blocks in the grid of the layer-1 activation kernel
+// (l1m_act_pool_moments_kernel<true>) split the conv3 / conv4 / dense weights into their bf16 planes and 16 clear the gradient
+// buffer.  Both jobs used to run on the side stream behind an event and were joined before conv3: two events on the main chain
+// (6-8 us each) for 12 us of work that hides under the activation pass.
 constexpr int kPrepSplitBlocks = 16, kPrepZeroBlocks = 16, kPrepBlocks = 3 * kPrepSplitBlocks + kPrepZeroBlocks;
-__global__ __launch_bounds__(256) void l1m_stats_prep_kernel(const float *__restrict__ feat, const float *__restrict__ wk, int B, int H, int W,
-                                                              int clips_per_wave, double *__restrict__ partial, int nstat, SplitDescs all,
-                                                              float *__restrict__ zero_buf, long zero_n)
-{
-    if ((int)blockIdx.x < nstat) { l1m_stats_body(feat, wk, B, H, W, clips_per_wave, partial); return; }
-    const int e = blockIdx.x - nstat;
-    if (e < 3 * kPrepSplitBlocks) { weight_split_slice(all.d[e / kPrepSplitBlocks], e % kPrepSplitBlocks, kPrepSplitBlocks); return; }
-    if (zero_buf)
-        for (long i = (long)(e - 3 * kPrepSplitBlocks) * 256 + threadIdx.x; i < zero_n; i += (long)kPrepZeroBlocks * 256) zero_buf[i] = 0.f;
-}
 
 // ---- forward ------------------------------------------------------------------------------------------------
 // zero_grads (training, split precision): the gradient buffer of the backward pass that follows is cleared on the side
 // stream beside the weight split instead of on the main chain; *zeroed tells the caller whether that happened
 int cnn_forward(const kws_model *m, const float *feat, int B, const float *params, float *state, CnnWs &w, bool training,
                 uint64_t seed, hipStream_t s, float *zero_grads = nullptr, bool *zeroed = nullptr, hipEvent_t overlap_event = nullptr,
-                void (*overlap_cb)(void *) = nullptr, void *overlap_user = nullptr)
+                void (*overlap_cb)(void *) = nullptr, void *overlap_user = nullptr, const double *moments = nullptr)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};   // conv input sizes
@@ -353,7 +346,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool bf16 = matrix_prec(m) == 1;
     ModelRes *R = nullptr;       // only the split-on-the-side-stream branch below needs the model's stream / events
     // training in split precision at a geometry the MFMA layer-1 kernels cover: the weight split and the gradient clear ride
-    // in the grid of the layer-1 statistics kernel (l1m_stats_prep_kernel) -- no side-stream branch, no events
+    // in the grid of the layer-1 activation kernel -- no side-stream branch, no events
     const bool prep_in_stats = bf16 && training && d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * kL1Stage &&
                                (d.H0 / 2) * (d.W0 / 2) <= 4 * kL1MaxTiles;
     if (prep_in_stats) {
@@ -390,16 +383,32 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         const long M1 = (long)B * d.H0 * d.W0;
         BnCoef k1 = coef_of(w.coef[0], 16);
         const float *kern1 = params + m->o_k[0];
-        if (training) {
-            if (l1m && prep_in_stats)
-                KWS_LAUNCH("l1m_stats_kernel", l1m_stats_prep_kernel, dim3(nbm + kPrepBlocks), dim3(256), smemm, s, feat, kern1, B, d.H0, d.W0, cpw, w.partial,
-                           nbm, split_descs(m, params, w), zero_grads, (long)m->P);
-            else if (l1m) KWS_LAUNCH("l1m_stats_kernel", l1m_stats_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, B, d.H0, d.W0, cpw, w.partial);
-            else KWS_LAUNCH("l1_stats_kernel", l1_stats_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, B, d.H0, d.W0, cpb, w.partial);
-            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", 1), bn_finalize_train_kernel, dim3(16), dim3(64), 0, s, w.partial, l1m ? nbm : nb, M1, 16,
+        if (training && l1m) {
+            // batch statistics of BatchNorm 1 from the second moments Q of the features (kws_layer1_moments.h): no statistics pass
+            // over z1, no finalize launch; Q comes from the caller (input pipeline) or is computed here
+            const double *q = moments;
+            if (!q) {
+                KWS_LAUNCH("l1_moments_kernel", l1_moments_kernel, dim3(nbm), dim3(256), smemm, s, feat, B, d.H0, d.W0, cpw, w.partial);
+                KWS_LAUNCH("l1_moments_finalize_kernel", l1_moments_finalize_kernel, dim3(kMomCount), dim3(64), 0, s, w.partial, nbm, w.moments);
+                q = w.moments;
+            }
+            L1PrepArgs pa{};
+            if (prep_in_stats) {
+                pa.all = split_descs(m, params, w); pa.zero_buf = zero_grads; pa.zero_n = (long)m->P;
+                pa.nsplit = kPrepSplitBlocks; pa.nzero = kPrepZeroBlocks;
+                KWS_LAUNCH("l1m_act_pool_kernel", l1m_act_pool_moments_kernel<true>, dim3(nbm + kPrepBlocks), dim3(256), smemm, s, feat, kern1, q,
+                           params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1, w.a[0], B, d.H0, d.W0, cpw, nbm, pa);
+            } else {
+                KWS_LAUNCH("l1m_act_pool_kernel", l1m_act_pool_moments_kernel<false>, dim3(nbm), dim3(256), smemm, s, feat, kern1, q,
+                           params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1, w.a[0], B, d.H0, d.W0, cpw, nbm, pa);
+            }
+        } else if (training) {
+            KWS_LAUNCH("l1_stats_kernel", l1_stats_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, B, d.H0, d.W0, cpb, w.partial);
+            KWS_LAUNCH(prof_name("bn_finalize_train_kernel", 1), bn_finalize_train_kernel, dim3(16), dim3(64), 0, s, w.partial, nb, M1, 16,
                        params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1);
         }
-        if (l1m) KWS_LAUNCH("l1m_act_pool_kernel", l1m_act_pool_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
+        if (training && l1m) ;
+        else if (l1m) KWS_LAUNCH("l1m_act_pool_kernel", l1m_act_pool_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
                    d.H0, d.W0, cpw);
         else KWS_LAUNCH("l1_act_pool_kernel", l1_act_pool_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
                    d.H0, d.W0, cpb);
@@ -491,7 +500,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
 
 // ---- backward -----------------------------------------------------------------------------------------------
 int cnn_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
-                 hipEvent_t bucket_event, hipStream_t s, float *stats, bool grads_zeroed = false)
+                 hipEvent_t bucket_event, hipStream_t s, float *stats, bool grads_zeroed = false, const double *moments = nullptr)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
@@ -649,12 +658,12 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         BnCoef k1 = coef_of(w.coef[0], 16);
         const float *kern1 = params + m->o_k[0];
         if (l1m) {
-            KWS_LAUNCH("l1m_bwd_reduce_kernel", l1m_bwd_reduce_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
-                       cpw, w.partial);
-            KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", 1), bn_bwd_finalize_kernel, dim3(16), dim3(64), 0, s, w.partial, nbm, M1, 16,
-                       params + m->o_g[0], grads + m->o_g[0], grads + m->o_b[0], k1);
-            KWS_LAUNCH("l1m_bwd_wgrad_kernel", l1m_bwd_wgrad_kernel, dim3(det ? 1 : nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, params + m->o_g[0],
-                       grads + m->o_k[0], B, d.H0, d.W0, det ? (B + 3) / 4 : cpw);
+            // one pass collects G, sum g, sum g z per block (double partials, fixed order); the closed forms of dW1, dgamma, dbeta use Q
+            const double *q = moments ? moments : w.moments;
+            KWS_LAUNCH("l1m_bwd_onepass_kernel", l1m_bwd_onepass_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0, cpw,
+                       w.partial);
+            KWS_LAUNCH("l1_bwd_finalize_moments_kernel", l1_bwd_finalize_moments_kernel, dim3(144 + 16), dim3(64), 0, s, w.partial, nbm, q, kern1,
+                       params + m->o_g[0], k1, grads + m->o_k[0], grads + m->o_g[0], grads + m->o_b[0]);
         } else {
             KWS_LAUNCH("l1_bwd_reduce_kernel", l1_bwd_reduce_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
                        cpb, w.partial);
@@ -971,6 +980,32 @@ int default_infer_precision() { return g_infer_precision; }
 
 extern "C" {
 
+int64_t kws_feature_moments_workspace_bytes(int B)
+{
+    (void)B;
+    return (int64_t)sizeof(double) * kMomCount * kStatStride;
+}
+
+int kws_feature_moments(const float *feat, int B, int n_features, int feature_size, double *moments, void *ws, size_t ws_bytes,
+                        void *stream)
+{
+    if (!feat || !moments || !ws) return fail(KWS_ERR_INVALID, "null argument");
+    if (B < 1 || n_features < 1 || feature_size < 1) return fail(KWS_ERR_INVALID, "bad shape");
+    const int H = n_features, W = feature_size;
+    if (H % 2 || W % 2 || (H + 2) * (W + 2) > 64 * kL1Stage || (H / 2) * (W / 2) > 4 * kL1MaxTiles)
+        return fail(KWS_ERR_UNSUPPORTED, "feature moments cover even maps up to (H+2)(W+2) <= %d (got %d x %d)", 64 * kL1Stage, H, W);
+    if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(KWS_ERR_INVALID, "workspace must be 256-byte aligned");
+    if (ws_bytes < (size_t)kws_feature_moments_workspace_bytes(B)) return fail(KWS_ERR_WORKSPACE, "workspace too small for the moment partial sums");
+    const int cpw = std::max(1, (B + 4 * kMaxStatBlocks - 1) / (4 * kMaxStatBlocks)), nbm = (B + 4 * cpw - 1) / (4 * cpw);
+    const size_t smemm = sizeof(float) * 4 * (size_t)((((H + 2) * (W + 2)) + 3) & ~3);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double *partial = static_cast<double *>(ws);
+    KWS_LAUNCH("l1_moments_kernel", l1_moments_kernel, dim3(nbm), dim3(256), smemm, s, feat, B, H, W, cpw, partial);
+    KWS_LAUNCH("l1_moments_finalize_kernel", l1_moments_finalize_kernel, dim3(kMomCount), dim3(64), 0, s, partial, nbm, moments);
+    KWS_LAUNCH_CHECK("feature moments");
+    return KWS_OK;
+}
+
 int kws_model_set_precision(kws_model *m, int matrix, int infer)
 {
     if (!m) return fail(KWS_ERR_INVALID, "null argument");
@@ -1124,7 +1159,7 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     bool grads_zeroed = false;     // cleared beside the weight split (the main chain joins that branch before conv3)
     rc = lite ? lite_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s)
               : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s, a->grads, &grads_zeroed,
-                            static_cast<hipEvent_t>(a->overlap_event), a->overlap_callback, a->overlap_user);
+                            static_cast<hipEvent_t>(a->overlap_event), a->overlap_callback, a->overlap_user, a->feat_moments);
     if (rc) return rc;
     if (lite && a->overlap_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->overlap_event), s));
     if (lite && a->overlap_callback) a->overlap_callback(a->overlap_user);
@@ -1137,7 +1172,7 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
     return lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
                 : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s,
-                               fuse_stats ? a->stats : nullptr, grads_zeroed);
+                               fuse_stats ? a->stats : nullptr, grads_zeroed, a->feat_moments);
 }
 
 int kws_set_matrix_precision(int mode)

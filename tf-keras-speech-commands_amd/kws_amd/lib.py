@@ -40,7 +40,7 @@ class KwsTrainArgs(ctypes.Structure):
                 ("ws_bytes", ctypes.c_size_t), ("dropout_seed", ctypes.c_uint64), ("grad_scale", ctypes.c_float),
                 ("probs", ctypes.c_void_p), ("stats", ctypes.c_void_p), ("bucket_event", ctypes.c_void_p),
                 ("forward_event", ctypes.c_void_p), ("overlap_event", ctypes.c_void_p),
-                ("overlap_callback", OVERLAP_CB), ("overlap_user", ctypes.c_void_p)]
+                ("overlap_callback", OVERLAP_CB), ("overlap_user", ctypes.c_void_p), ("feat_moments", ctypes.c_void_p)]
 
 
 MODEL_KINDS = {"simple_cnn": 0, "simple_cnn_lite": 1, "simple_gru": 2, "simple_lstm": 3}
@@ -89,6 +89,9 @@ def get_lib():
     L.kws_model_workspace_bytes.restype = i64
     L.kws_model_forward.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, vp]
     L.kws_model_train_fwd_bwd.argtypes = [vp, ctypes.POINTER(KwsTrainArgs), vp]
+    L.kws_feature_moments_workspace_bytes.argtypes = [i32]
+    L.kws_feature_moments_workspace_bytes.restype = i64
+    L.kws_feature_moments.argtypes = [vp, i32, i32, i32, vp, vp, ctypes.c_size_t, vp]
     L.kws_model_grad_split.argtypes = [vp]
     L.kws_model_grad_split.restype = i64
     L.kws_loss_forward.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp]
@@ -156,6 +159,7 @@ def device_count():
 
 MATRIX_FP32, MATRIX_BF16X6 = 0, 1
 INFER_FP32, INFER_FP16 = 0, 1
+FEATURE_MOMENTS = 100
 COMM_ID_BYTES = 128
 DT_F32, DT_F64, DT_I32, DT_I64 = 0, 1, 2, 3
 OP_SUM, OP_MAX, OP_AVG = 0, 1, 2

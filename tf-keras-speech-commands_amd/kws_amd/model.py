@@ -61,6 +61,31 @@ class ModelSpec(object):
             pass
 
 
+class FeatureMoments(object):
+    """kws_feature_moments: the 10 x 10 second-moment matrix of a feature batch (include/kws.h), on the current stream."""
+
+    def __init__(self, n_features, feature_size, device=None):
+        torch = _torch()
+        self._L = _l.get_lib()
+        self.n_features, self.feature_size = int(n_features), int(feature_size)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        need = int(self._L.kws_feature_moments_workspace_bytes(1))
+        self._ws = torch.empty((need + 256,), dtype=torch.uint8, device=dev)
+        self._dev = dev
+
+    def __call__(self, feat, out=None):
+        torch = _torch()
+        n = self.n_features * self.feature_size
+        B = feat.numel() // n
+        if out is None:
+            out = torch.empty((_l.FEATURE_MOMENTS,), dtype=torch.float64, device=self._dev)
+        base = self._ws.data_ptr()
+        aligned = (base + 255) & ~255
+        _l.check(self._L.kws_feature_moments(feat.data_ptr(), B, self.n_features, self.feature_size, out.data_ptr(), aligned,
+                                             self._ws.numel() - (aligned - base), torch.cuda.current_stream().cuda_stream))
+        return out
+
+
 class DeviceModel(object):
     """Flat parameter / state / gradient / Adam buffers on the current HIP device + the compute entry points."""
 
@@ -160,10 +185,12 @@ class DeviceModel(object):
         return probs, am
 
     def train_fwd_bwd(self, feat, labels, class_weights=None, dropout_seed=0, grad_scale=1.0, want_probs=False,
-                      ignore_index=0, bucket_event=None, forward_event=None, overlap_event=None, overlap_callback=None):
+                      ignore_index=0, bucket_event=None, forward_event=None, overlap_event=None, overlap_callback=None,
+                      feat_moments=None):
         """labels: CUDA int32 (B,); class_weights: CUDA float32 (C,) or None.  Leaves grads in self.grads and
         {sum of losses, top-1 hits} in self.stats (device).  bucket_event: torch.cuda.Event recorded when the early
-        gradient bucket [grad_split, P) is final."""
+        gradient bucket [grad_split, P) is final.  feat_moments: the float64 CUDA tensor feature_moments(feat) returned (optional;
+        simple_cnn then skips its own moment pass at the head of the step)."""
         torch = _torch()
         B = self._check_feat(feat)
         if labels.dtype != torch.int32 or not labels.is_cuda or labels.numel() != B:
@@ -179,6 +206,10 @@ class DeviceModel(object):
         a.dropout_seed, a.grad_scale = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, float(grad_scale)
         a.probs = probs.data_ptr() if want_probs else None
         a.stats = self.stats.data_ptr()
+        if feat_moments is not None:
+            if feat_moments.dtype != torch.float64 or not feat_moments.is_cuda or feat_moments.numel() != _l.FEATURE_MOMENTS:
+                raise ValueError("feat_moments must be the %d float64 values of feature_moments()" % _l.FEATURE_MOMENTS)
+            a.feat_moments = feat_moments.data_ptr()
         for ev in (bucket_event, forward_event, overlap_event):
             if ev is not None and not ev.cuda_event:
                 ev.record()                     # torch creates the hipEvent_t lazily; an un-recorded Event has no handle yet

@@ -12,7 +12,7 @@ def _torch():
 
 
 class FeaturePipeline(object):
-    def __init__(self, featurizer, batch, n_features, feature_size, device="cuda"):
+    def __init__(self, featurizer, batch, n_features, feature_size, device="cuda", moments=False):
         torch = _torch()
         self.featurizer = featurizer
         # the featurizer shares the chip with the train step here: half of each CU's LDS (kws_featurizer_set_cu_share), so the
@@ -25,6 +25,13 @@ class FeaturePipeline(object):
         self.free = [None, None]                                  # the step that read the buffer is complete (recorded on main)
         self.n_submitted = 0
         self.n_taken = 0
+        # moments=True: the second moments simple_cnn's first layer needs (kws_feature_moments) are computed right behind the
+        # featurizer on the side stream; take() then returns (features, moments) for DeviceModel.train_fwd_bwd(feat_moments=...)
+        self.moments = None
+        if moments:
+            from .model import FeatureMoments
+            self.moments = FeatureMoments(n_features, feature_size)
+            self.mom_bufs = [torch.empty((100,), dtype=torch.float64, device=device) for _ in range(2)]
 
     def submit(self, wav, valid_len=None, after=None):
         """Enqueue the featurization of one batch on the side stream (returns at once).  `after`: an event on the main
@@ -42,6 +49,8 @@ class FeaturePipeline(object):
             self.side.wait_event(self.free[i])
         with torch.cuda.stream(self.side):
             self.featurizer(wav, valid_len=valid_len, out=self.bufs[i])
+            if self.moments is not None:
+                self.moments(self.bufs[i], out=self.mom_bufs[i])
             self.ready[i].record(self.side)
         self.n_submitted += 1
 
@@ -53,6 +62,8 @@ class FeaturePipeline(object):
         i = self.n_taken % 2
         torch.cuda.current_stream().wait_event(self.ready[i])
         self.n_taken += 1
+        if self.moments is not None:
+            return self.bufs[i], self.mom_bufs[i]
         return self.bufs[i]
 
     def release(self):

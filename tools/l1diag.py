@@ -1,0 +1,27 @@
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tf-keras-speech-commands_amd")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+from kws_amd import lib as L
+from oracle import model_oracle as mo
+import test_model_gpu as T
+C, B = 36, 96
+om, dm = T.build("simple_cnn", C)
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+x = T.features(B, SEED)
+y = np.random.default_rng(8).integers(0, C, B)
+mo.train_forward_backward(om, x.astype(np.float64), y)
+want = om.grad_list()
+xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
+res = {}
+for mode in (L.MATRIX_BF16X6, L.MATRIX_FP32):
+    dm.set_precision(matrix=mode)
+    for rep in range(2):
+        dm.train_fwd_bwd(xt, yt)
+        res[(mode, rep)] = [g.copy() for g in dm.get_grads()]
+names = [t["name"] for t in dm.spec.tensors if t["trainable"]]
+worst = {}
+for i, n in enumerate(names):
+    w = want[i]; s = np.abs(w).max()
+    a, a2, b = res[(1, 0)][i], res[(1, 1)][i], res[(0, 0)][i]
+    print("%-28s vs oracle: bf16 %.2e fp32 %.2e | bf16 vs fp32 %.2e | run-to-run %.2e" % (n, np.abs(a - w).max() / s, np.abs(b - w).max() / s, np.abs(a - b).max() / s, np.abs(a - a2).max() / s))

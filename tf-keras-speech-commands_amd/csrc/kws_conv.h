@@ -1299,7 +1299,8 @@ __global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(float *__restrict_
 // budget, two blocks per CU).  The ten pixel tiles of a 15 x 10 map do not divide over four waves, so the tile a wave
 // starts with rotates from clip to clip and every SIMD sees the same load over time.
 // COMPACT: g arrives as (routed value per pool window, element index) -- bn.gw / bn.arg -- and is rebuilt while staging
-template <bool BN, bool COMPACT = false>
+// STORE_DZ = false: dz is not written back (the weight gradient forms it itself, conv_wgrad_clip_bf16_kernel<true>)
+template <bool BN, bool COMPACT = false, bool STORE_DZ = true>
 __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__restrict__ dz, const float *__restrict__ wgt,
                                                                        float *__restrict__ dx, int B, int H, int W, BnBwdArgs bn)
 {
@@ -1392,7 +1393,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__r
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (cq[j] >= 0 && (int)((pa[j] >> (8 * e)) & 0xFFu) == ce[j]) ? v[e] : 0.f;
                 }
-                if (BN) { v = bn_apply(v, pz[j]); dst[i] = v; }
+                if (BN) { v = bn_apply(v, pz[j]); if (STORE_DZ) dst[i] = v; }
                 stage(i, v);
             }
         }
@@ -1436,8 +1437,12 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__r
 // ds_read_b64_tr_b16; every lane supplies the address of one pixel row, so the tap shift of x is an immediate offset and
 // 8 consecutive pixels per 32-lane half fall into 8 different bank octets.  Wave = (column tile nt, tap parity): it keeps
 // the accumulators of its 5 or 4 taps for the whole kernel and reuses each dz fragment for all of them.
+// GBN: dz is not read but formed while staging from the compact routed gradient (bn.gw / bn.arg, bn_bwd_reduce_pool_kernel<true>)
+// and z (BatchNorm backward: dz = gamma inv (g - k2 - xhat k3)), exactly as conv_dgrad_clip_bf16_kernel<true, true> does -- the
+// weight gradient then does not wait for the data-gradient kernel and starts beside it on the side stream.
+template <bool GBN = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_clip_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dz,
-                                                                       float *__restrict__ dw, int B, int H, int W)
+                                                                       float *__restrict__ dw, int B, int H, int W, BnBwdArgs bn)
 {
     constexpr int CIN = 16, COUT = 32, KS = 5;                    // k-steps of 32 pixels: H * W <= 160
     extern __shared__ __attribute__((aligned(16))) unsigned char ctile[];
@@ -1474,14 +1479,55 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_clip_bf16_kernel(const floa
 
     constexpr int PX = 3, PD = 5;                                 // float4 per thread: x (<= 768 per clip), dz (<= 1280)
     const int nx4 = HW * (CIN / 4), nd4 = HW * (COUT / 4);
-    f32x4 px[PX], pd[PD];
+    f32x4 px[PX], pd[PD], pz[GBN ? PD : 1];
+    unsigned pa[GBN ? PD : 1];                                    // GBN: the four element indices of the float4's pool window
+    constexpr int F4 = COUT / 4;
+    float gi[4], mean[4], inv[4], k2[4], k3[4];                   // GBN: BatchNorm coefficients of this thread's 4 channels
+    const int Wp = W / 2, nwin = (H / 2) * Wp;
+    int cq[GBN ? PD : 1], ce[GBN ? PD : 1];
+    if (GBN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (threadIdx.x % F4) + e;
+            inv[e] = bn.inv[c]; gi[e] = bn.gamma[c] * inv[e]; mean[e] = bn.mean[c]; k2[e] = bn.k2[c]; k3[e] = bn.k3[c];
+        }
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            const int i = threadIdx.x + 256 * j, pix = i / F4, c4 = i % F4, y = pix / W, xx = pix - y * W;
+            const bool in = i < nd4 && y < 2 * (H / 2) && xx < 2 * Wp;
+            cq[j] = in ? ((y >> 1) * Wp + (xx >> 1)) * F4 + c4 : -1;
+            ce[j] = (y & 1) * 2 + (xx & 1);
+        }
+    }
     auto prefetch = [&](int b) {
         const f32x4 *xs = reinterpret_cast<const f32x4 *>(x + (long)b * HW * CIN);
-        const f32x4 *ds = reinterpret_cast<const f32x4 *>(dz + (long)b * HW * COUT);
 #pragma unroll
         for (int j = 0; j < PX; ++j) { const int i = threadIdx.x + 256 * j; px[j] = i < nx4 ? xs[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        if (GBN) {
+            const f32x4 *zs = reinterpret_cast<const f32x4 *>(bn.z + (long)b * HW * COUT);
+            const f32x4 *gws = reinterpret_cast<const f32x4 *>(bn.gw) + (long)b * nwin * F4;
+            const unsigned *ars = reinterpret_cast<const unsigned *>(bn.arg) + (long)b * nwin * F4;
 #pragma unroll
-        for (int j = 0; j < PD; ++j) { const int i = threadIdx.x + 256 * j; pd[j] = i < nd4 ? ds[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            for (int j = 0; j < PD; ++j) {
+                const int i = threadIdx.x + 256 * j, q = cq[j] >= 0 ? cq[j] : 0;
+                pd[j] = gws[q];
+                pa[j] = ars[q];
+                pz[j] = i < nd4 ? zs[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            const f32x4 *ds = reinterpret_cast<const f32x4 *>(dz + (long)b * HW * COUT);
+#pragma unroll
+            for (int j = 0; j < PD; ++j) { const int i = threadIdx.x + 256 * j; pd[j] = i < nd4 ? ds[i] : (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+    };
+    auto form_dz = [&](int j) {                                   // GBN: g of this float4 from its window's routed value, then BatchNorm backward
+        f32x4 v = pd[j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g = (cq[j] >= 0 && (int)((pa[j] >> (8 * e)) & 0xFFu) == ce[j]) ? v[e] : 0.f;
+            v[e] = gi[e] * (g - k2[e] - (pz[j][e] - mean[e]) * inv[e] * k3[e]);
+        }
+        return v;
     };
     auto stage_x = [&](int i, f32x4 v) {
         const int pix = i >> 2, c4 = i & 3, y = pix / W, xx = pix - y * W;
@@ -1507,8 +1553,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_clip_bf16_kernel(const floa
 #pragma unroll
         for (int j = 0; j < PX; ++j) { const int i = threadIdx.x + 256 * j; if (i < nx4) stage_x(i, px[j]); }
 #pragma unroll
-        for (int j = 0; j < PD; ++j) { const int i = threadIdx.x + 256 * j; if (i < nd4) stage_d(i, pd[j]); }
-        if (nx4 > 256 * PX || nd4 > 256 * PD) {                   // larger clips: the remainder goes straight through
+        for (int j = 0; j < PD; ++j) { const int i = threadIdx.x + 256 * j; if (i < nd4) stage_d(i, GBN ? form_dz(j) : pd[j]); }
+        if (!GBN && (nx4 > 256 * PX || nd4 > 256 * PD)) {         // larger clips: the remainder goes straight through (GBN: the host checks the size)
             const f32x4 *xs = reinterpret_cast<const f32x4 *>(x + (long)b * HW * CIN);
             for (int i = threadIdx.x + 256 * PX; i < nx4; i += 256) stage_x(i, xs[i]);
             const f32x4 *ds = reinterpret_cast<const f32x4 *>(dz + (long)b * HW * COUT);

@@ -621,10 +621,27 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const size_t smd = sizeof(float) * (size_t)(H1 + 2) * (W1 + 2) * (32 + 4);
             BnBwdArgs bn = {w.z[1], params + m->o_g[1], k.mean, k.inv, k.k2, k.k3};
             if (compact_g) { bn.gw = w.da[1]; bn.arg = reinterpret_cast<const unsigned char *>(w.da[2]); }
+            const bool wgrad_bf16 = mprec == 1 && H1 * W1 <= 160;
+            // compact g and a clip that fits the kernels' register staging: the weight gradient forms dz itself (from the routed g
+            // and z2), so it forks BEFORE the data gradient and runs beside it and beside layer 1 on the side stream; the data
+            // gradient then does not write dz back
+            const bool wgrad_early = compact_g && wgrad_bf16 && H1 * W1 * 8 <= 1280 && H1 * W1 * 4 <= 768;
+            const size_t smwb = std::max((size_t)3 * 32 * (H1 + 2) * (W1 + 2) + (size_t)6 * 32 * (H1 * W1 + 1), sizeof(float) * 9 * 16 * 32);
+            // two blocks per CU although three fit: the third takes the LDS the layer-1 kernels of the main chain need beside it
+            // (same-box A/B: 0.785 ms/step with one or two, 0.800 with three); deterministic: one persistent block walks every clip
+            auto wgrad_grid = [&](int occ) { return dim3(det ? 1u : even_grid(cu_count() * std::min(occ, 2))); };
+            if (wgrad_early) {
+                if (int rc = fork(1)) return rc;
+                static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel<true>, 256, smwb);
+                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel<true>, wgrad_grid(occ), dim3(256), smwb, s2, in, nullptr, dk, B, H1, W1, bn);
+            }
             if (mprec == 1) {
                 // split-precision form: 2 blocks per CU by registers (the weight fragments of all nine taps stay in them)
                 const size_t smdb = (size_t)12 * 16 * (((H1 + 2) * (W1 + 2) + 15) & ~15);
-                if (compact_g)
+                if (wgrad_early)
+                    KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true, false>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s,
+                               w.gz[1], kern, w.da[0], B, H1, W1, bn);
+                else if (compact_g)
                     KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s,
                                w.gz[1], kern, w.da[0], B, H1, W1, bn);
                 else
@@ -632,17 +649,16 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                                w.gz[1], kern, w.da[0], B, H1, W1, bn);
             } else
                 KWS_LAUNCH("conv_dgrad_clip<32,16>", (conv_dgrad_clip_kernel<32, true>), dim3(nblk_d), dim3(256), smd, s, w.gz[1], kern, w.da[0], B, H1, W1, bn);
-            if (int rc = fork(1)) return rc;
-            if (mprec == 1 && H1 * W1 <= 160) {
-                const size_t smwb = std::max((size_t)3 * 32 * (H1 + 2) * (W1 + 2) + (size_t)6 * 32 * (H1 * W1 + 1), sizeof(float) * 9 * 16 * 32);
-                // two blocks per CU although three fit: the third takes the LDS the layer-1 kernels of the main chain need beside it
-                // (same-box A/B: 0.785 ms/step with one or two, 0.800 with three)
-                static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel, 256, smwb);
-                // deterministic: one persistent block walks every clip, so dW2 is a single add onto the cleared buffer
-                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel, dim3(det ? 1u : even_grid(cu_count() * std::min(occ, 2))), dim3(256), smwb, s2, in,
-                           w.gz[1], dk, B, H1, W1);
-            } else
+            if (wgrad_early) {
+                ;
+            } else if (wgrad_bf16) {
+                if (int rc = fork(1)) return rc;
+                static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel<false>, 256, smwb);
+                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel<false>, wgrad_grid(occ), dim3(256), smwb, s2, in, w.gz[1], dk, B, H1, W1, bn);
+            } else {
+                if (int rc = fork(1)) return rc;
                 KWS_LAUNCH("conv_wgrad_clip<16,32>", conv_wgrad_clip_kernel<32>, dim3(det ? 1u : nblk), dim3(256), smw2, s2, in, w.gz[1], dk, B, H1, W1);
+            }
         }
     }
     // layer 1: da1 -> (dgamma1, dbeta1, dW1) with conv1 recomputed; no z1-sized tensor is read or written

@@ -44,6 +44,14 @@ def features(B, seed):
     return x.astype(np.float32)
 
 
+def grads_match(dm, om, tol):
+    """worst relative error (per tensor, relative to the tensor's largest entry) of the device gradients against the oracle's"""
+    worst = 0.0
+    for g, want in zip(dm.get_grads(), om.grad_list()):
+        worst = max(worst, rel_err(g, want))
+    return worst < tol, worst
+
+
 def test_tensor_table_is_keras_order(torch):
     from kws_amd.model import ModelSpec
     from oracle import model_oracle as mo
@@ -74,8 +82,10 @@ def test_cnn_train_forward_backward(torch, weighted, seed):
     x = features(B, 5)
     y = np.random.default_rng(6).integers(0, C, B)
     cw = np.array([0.3] + [0.7 / (C - 1)] * (C - 1)) if weighted else None
+    from tie_aware import TieAwareOracle
     state0 = [w.copy() for w in om.get_weights()]
-    loss, acc, p = mo.train_forward_backward(om, x.astype(np.float64), y, cw, dropout_seed=seed or None)
+    tao = TieAwareOracle(om, x.astype(np.float64), y, cw, seed or None)
+    loss, acc, p = tao.loss, tao.acc, tao.probs
     probs = dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda(),
                              torch.from_numpy(cw.astype(np.float32)).cuda() if weighted else None, dropout_seed=seed,
                              want_probs=True)
@@ -83,11 +93,8 @@ def test_cnn_train_forward_backward(torch, weighted, seed):
     np.testing.assert_allclose(probs.cpu().numpy(), p, atol=1e-4, rtol=0)
     assert abs(stats[0] / B - loss) < 1e-4
     assert stats[1] == round(acc * B)
-    worst = 0.0
-    for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
-        e = rel_err(g, want)
-        worst = max(worst, e)
-        assert e < 2e-4, "gradient of layer %d %s: rel err %g" % (li, n, e)
+    ok, label, err, base_err = tao.match(dm.get_grads(), 2e-5)       # every tensor within 2e-5 of its largest entry (tests/tie_aware.py)
+    assert ok, "gradients match no resolution of the oracle's near ties: best '%s' %g (baseline %g)" % (label, err, base_err)
     # BatchNormalization moving statistics were updated like Keras does (momentum 0.99, unbiased variance)
     got_w = dm.get_weights()
     for i, (li, n, t) in enumerate(om.weight_list()):
@@ -370,14 +377,20 @@ def test_cnn_full_batch_4096_grids(torch):
     from oracle import model_oracle as mo
     C = 36
     om, dm = build("simple_cnn", C)
+    # B = 512 against the oracle, exact about the discontinuities (tests/tie_aware.py): the device gradient has to match the
+    # oracle's for the baseline resolution of its near-tie decisions or for one / two of them flipped -- to 2e-4, not the 1e-3
+    # a rerouted element would need
+    from tie_aware import TieAwareOracle
     B = 512
+    om, dm = build("simple_cnn", C)
     x = features(B, 41)
     y = np.random.default_rng(42).integers(0, C, B)
-    loss, acc, _ = mo.train_forward_backward(om, x.astype(np.float64), y)
+    tao = TieAwareOracle(om, x.astype(np.float64), y)
     dm.train_fwd_bwd(torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda())
-    assert abs(float(dm.stats[0].item()) / B - loss) < 1e-4
-    for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
-        assert rel_err(g, want) < 1e-3, (li, n, rel_err(g, want))   # fp32 sums over 512*600 terms per conv1 weight
+    assert abs(float(dm.stats[0].item()) / B - tao.loss) < 1e-4
+    ok, label, err, base_err = tao.match(dm.get_grads(), 2e-4)
+    print("B = 512: %d near-tie decisions in the oracle; device matches '%s' to %.1e (baseline %.1e)" % (tao.n_near_ties, label, err, base_err))
+    assert ok, (label, err, base_err)
     B = 4096
     x = features(B, 43)
     y = np.random.default_rng(44).integers(0, C, B).astype(np.int32)
@@ -391,9 +404,10 @@ def test_cnn_full_batch_4096_grids(torch):
     assert abs(l1 - float(dm.stats[0].item())) < 1e-3 * abs(l1)
     for a, b2, t in zip(g1, g2, [t for t in dm.spec.tensors if t["trainable"]]):
         assert np.all(np.isfinite(a)) and np.abs(a).max() > 0, t["name"]
-        # float atomics and the order of the BatchNorm sums change with the permutation; conv1's gradient additionally sees
-        # the rare pool arg-max tie flip, measured up to 1.4e-4 of its largest entry
-        assert rel_err(b2, a) < (3e-4 if t["name"] == "conv2d/kernel" else 1e-4), (t["name"], rel_err(b2, a))
+        # float atomics and the order of the BatchNorm sums change with the permutation, and with them which of the batch's
+        # ~4e7 gate / arg-max decisions sit on the other side of their threshold (tests/tie_aware.py): a
+        # rerouted element moves a layer-1 / layer-2 tensor by up to 2.3e-4 of its largest entry at this batch size (measured)
+        assert rel_err(b2, a) < 5e-4, (t["name"], rel_err(b2, a))
     # and against a fresh single-GPU "two halves" estimate: the head/dense gradients of a 4096 batch are NOT the mean of
     # two 2048 halves (BatchNormalization couples the clips), so no such check is made here.
 
@@ -404,18 +418,14 @@ def test_matrix_precision_modes_agree(torch):
     tolerances; unknown modes are refused."""
     from kws_amd import lib as L
     from oracle import model_oracle as mo
-    C = 36
-    om, dm = build("simple_cnn", C)
-    B = 96
-    # (seed 7 of this generator puts one conv4 pre-activation within float32 rounding of its ReLU gate: the split-precision and the
-    # fp32 products then land on different sides of it and the routed gradient of that element moves -- the discontinuity DESIGN.md
-    # section 4 describes, not an arithmetic difference; tools/l1diag.py shows 1e-6 agreement on every other seed tried)
-    x = features(B, 17)
-    y = np.random.default_rng(8).integers(0, C, B)
-    want_loss, _, _ = mo.train_forward_backward(om, x.astype(np.float64), y)
-    want_grads = om.grad_list()
-    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
+    from tie_aware import TieAwareOracle
+    C, B = 36, 96
     assert L.get_matrix_precision() == L.MATRIX_BF16X6
+    om, dm = build("simple_cnn", C)
+    x = features(B, 7)       # a batch with a conv4 pre-activation within float32 rounding of its ReLU gate (tools/l1diag.py)
+    y = np.random.default_rng(8).integers(0, C, B)
+    tao = TieAwareOracle(om, x.astype(np.float64), y)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
     res = {}
     try:
         for mode in (L.MATRIX_BF16X6, L.MATRIX_FP32):
@@ -428,12 +438,17 @@ def test_matrix_precision_modes_agree(torch):
     finally:
         L.set_matrix_precision(L.MATRIX_BF16X6)
     (p6, g6, l6), (p32, g32, l32) = res[L.MATRIX_BF16X6], res[L.MATRIX_FP32]
-    assert abs(l6 - l32) < 2e-6 and abs(l6 - want_loss) < 1e-4
+    assert abs(l6 - l32) < 2e-6 and abs(l6 - tao.loss) < 1e-4        # forward values are continuous in the rounding
     np.testing.assert_allclose(p6, p32, rtol=0, atol=2e-6)
-    for a, b, w in zip(g6, g32, want_grads):
-        scale = np.abs(w).max() + 1e-12
-        assert np.abs(a - b).max() / scale < 2e-5          # the two arithmetic paths differ by fp32 rounding only
-        assert np.abs(a - w).max() / scale < 2e-4 and np.abs(b - w).max() / scale < 2e-4
+    labels = []
+    for name, g in (("bf16x6", g6), ("fp32", g32)):
+        ok, label, err, base_err = tao.match(g, 2e-5)               # fp32-level agreement with SOME resolution of the near ties
+        print("%s: matches '%s' to %.1e (baseline %.1e)" % (name, label, err, base_err))
+        assert ok, (name, label, err, base_err)
+        labels.append(label)
+    if labels[0] == labels[1]:                                          # same resolution: the two paths differ by rounding only
+        for a, b2, w in zip(g6, g32, tao.base):
+            assert np.abs(a - b2).max() / (np.abs(w).max() + 1e-12) < 2e-5
 
 
 # ---- simple_lstm (classifier/models/rnn.py:46-79): LSTM(48, tanh, dropout 0.2) -> Dense softmax ---------------------------

@@ -175,3 +175,30 @@ def test_training_reduces_loss_on_separable_task():
             loss, acc = mo.train_step(m, opt, x, y, dropout_seed=it)
             l0 = loss if l0 is None else l0
         assert loss < 0.6 * l0, (mt, l0, loss)
+
+
+def test_tie_aware_matching_finds_a_flipped_decision():
+    """tests/tie_aware.py (used by the GPU parity tests): a gradient computed with ONE near-threshold decision resolved the other
+    way is matched by the corresponding alternative and by no other, and reported; an arbitrary perturbation matches nothing."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tie_aware import TieAwareOracle
+    m, x, y = make("simple_cnn", 6, seed=3, B=16)
+    tao = TieAwareOracle(m, x, y, eps=2e-3, max_candidates=6)          # a wide eps so that this small batch has candidates
+    assert len(tao.candidates) >= 2 and tao.n_near_ties >= len(tao.candidates)
+    alts = list(tao.alternatives())
+    assert alts[0][0] == "baseline"
+    ok, label, err, base = tao.match(tao.base, 1e-9)
+    assert ok and label == "baseline" and err == 0.0
+    # (a gate under a pool window's losing element carries no gradient: flipping it changes nothing; take one that does)
+    change = [max(np.abs(a - b).max() for a, b in zip(g, tao.base)) for _, g in alts]
+    k = next(i for i in range(1, len(alts)) if change[i] > 1e-6)
+    ok, label, err, base = tao.match(alts[k][1], 1e-9)
+    assert ok and base > 1e-6 and label != "baseline"
+    assert max(np.abs(a - b).max() for a, b in zip(alts[k][1], dict(alts)[label])) == 0.0
+    bad = [g * 1.01 for g in tao.base]
+    ok, label, err, base = tao.match(bad, 1e-4)
+    assert not ok
+    # the oracle is left with its baseline gradients
+    for g, b in zip(m.grad_list(), tao.base):
+        np.testing.assert_array_equal(g, b)

@@ -52,17 +52,37 @@ __global__ __launch_bounds__(256) void l1_moments_kernel(const float *__restrict
     for (int i = 0; i < count; ++i) {
         t.store();
         if (i + 1 < count) t.fetch(feat, first + i + 1);
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        int row = lq / W, col = lq - row * W;
-        for (int q = lq; q - lq < t.HW; q += 4) {
-            float a = t.xs[row * t.WP + col + toff];            // in bounds for every lane (row <= H - 1 + slack is clamped below)
-            a = li < 9 ? a : (li == 9 ? 1.f : 0.f);
-            a = q < t.HW ? a : 0.f;
-            d = mfma16(a, a, d);
-            col += 4;
-            while (col >= W) { col -= W; ++row; }
-            row = row < H ? row : H - 1;                        // lanes past the last pixel read a valid address and are masked
+        f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        const float *px = t.xs + lq + toff;
+        const float one = li == 9 ? 1.f : 0.f;
+        const bool tapl = li < 9;
+        if (W & 3) {
+            // general width: four consecutive pixels of the row-major map per step, the lane's pixel advanced without a division
+            int row = lq / W, col = lq - row * W;
+            for (int q = lq; q - lq < t.HW; q += 4) {
+                float a = tapl ? t.xs[row * t.WP + col + toff] : one;
+                a = q < t.HW ? a : 0.f;
+                d0 = mfma16(a, a, d0);
+                col += 4;
+                while (col >= W) { col -= W; ++row; }
+                row = row < H ? row : H - 1;                    // lanes past the last pixel read a valid address and are masked
+            }
+        } else
+        // W % 4 == 0: a row is W / 4 steps of four pixels, no per-lane index arithmetic inside the loop; two accumulators so that
+        // consecutive MFMAs do not wait for each other
+        for (int row = 0; row < H; ++row, px += t.WP) {
+            int cg = 0;
+            for (; cg + 8 <= W; cg += 8) {
+                const float a0 = tapl ? px[cg] : one, a1 = tapl ? px[cg + 4] : one;
+                d0 = mfma16(a0, a0, d0);
+                d1 = mfma16(a1, a1, d1);
+            }
+            if (cg < W) {
+                const float a0 = tapl ? px[cg] : one;
+                d0 = mfma16(a0, a0, d0);
+            }
         }
+        f32x4 d = d0 + d1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] += (double)d[r];
         __builtin_amdgcn_wave_barrier();
@@ -170,7 +190,8 @@ __global__ __launch_bounds__(256) void l1m_act_pool_moments_kernel(const float *
 // Backward of layer 1 in ONE pass over (features, da1): per block, in double,
 //   rows   0..143  G[t][c]  = sum g f(p+t)      (row = t * 16 + c)
 //   rows 144..159  SG[c]    = sum g
-//   rows 160..175  SGZ[c]   = sum g z           (z at the routed element)
+//   rows 160..175  SGZ[c]   = sum g (z - m)     (z at the routed element, centred by the float mean m = k.mean[c]: the raw sum g z
+//                                                cancels against mean * sum g and lost four digits in float per-clip partials)
 // to partial[row * kStatStride + blockIdx.x]; g = the gradient routed through max-pool and ReLU6 (same rule as every other pass).
 constexpr int kL1BwdRows = 9 * 16 + 32;
 __global__ __launch_bounds__(256, 4) void l1m_bwd_onepass_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(256, 4) void l1m_bwd_onepass_kernel(const float *__
     long first;
     int count;
     l1m_clips(B, clips_per_wave, first, count);
-    const float sc = k.scale[li], sh = k.shift[li];
+    const float sc = k.scale[li], sh = k.shift[li], zmean = k.mean[li];
     // B side of the G product: this lane supplies f at tap li (< 9) of the element's pixel in window 4 tile + lq
     const int tap = li < 9 ? li : 8, boff = (tap / 3) * t.WP + tap % 3;
     const float bmask = li < 9 ? 1.f : 0.f;
@@ -219,7 +240,7 @@ __global__ __launch_bounds__(256, 4) void l1m_bwd_onepass_kernel(const float *__
                     l1m_route(z, sc, sh, dcur[j], arg, g);      // da1 of a window past the clip was fetched as 0: g = 0 there
                     const float za = arg == 0 ? z[0] : arg == 1 ? z[1] : arg == 2 ? z[2] : z[3];
                     fs += g;
-                    fsz = fmaf(g, za, fsz);
+                    fsz = fmaf(g, za - zmean, fsz);
                     const float *xb = t.xs + t.d_window_offset(ok) + boff;
                     t.next_tile();
 #pragma unroll
@@ -259,8 +280,12 @@ __global__ void l1_bwd_finalize_moments_kernel(const double *__restrict__ partia
     const double sgz = wave_sum_partials(partial, 0, 1, 160 + c, nblk);
     const double gsum = row < 144 ? wave_sum_partials(partial, 0, 1, row, nblk) : 0.0;
     if (threadIdx.x != 0) return;
-    const double M = q[kMomCount - 1], mean = (double)k.mean[c], inv = (double)k.inv[c];
-    const double sgx = inv * (sgz - mean * sg);            // sum g xhat
+    const double M = q[kMomCount - 1], inv = (double)k.inv[c];
+    double mean = 0.0;                                     // the batch mean of z in double (the kernels centred with its float rounding)
+#pragma unroll
+    for (int u = 0; u < 9; ++u) mean += (double)wk[u * 16 + c] * q[u * kMomN + 9];
+    mean /= M;
+    const double sgx = inv * (sgz + ((double)k.mean[c] - mean) * sg);      // sum g xhat = inv * sum g (z - mean)
     if (row >= 144) {
         dbeta[c] = (float)sg;
         dgamma[c] = (float)sgx;

@@ -5,11 +5,11 @@ import numpy as np, torch
 from kws_amd import lib as L
 from oracle import model_oracle as mo
 import test_model_gpu as T
-C, B = 36, 96
+C, B = 36, int(sys.argv[2]) if len(sys.argv) > 2 else 96
 om, dm = T.build("simple_cnn", C)
 SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 x = T.features(B, SEED)
-y = np.random.default_rng(8).integers(0, C, B)
+y = np.random.default_rng(SEED + 1).integers(0, C, B)
 mo.train_forward_backward(om, x.astype(np.float64), y)
 want = om.grad_list()
 xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()

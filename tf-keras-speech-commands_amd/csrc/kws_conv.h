@@ -26,7 +26,12 @@ struct ConvGeom {
 };
 
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_BIAS_RELU6 = 2, EPI_BIAS = 3, EPI_BIAS_RELU = 4,
-       EPI_BN_RELU6 = 5 };   // inference: relu6(v * scale[n] + shift[n]), scale passed as `bias`, shift as `shift`
+       EPI_BN_RELU6 = 5,     // inference: relu6(v * scale[n] + shift[n]), scale passed as `bias`, shift as `shift`
+       // Data gradient whose consumer is the backward pass of the BatchNormalization -> ReLU6 IN FRONT of this convolution (no
+       // pooling between them): the epilogue gates the produced gradient by that ReLU6 (y = z * scale + shift in (0, 6), z read
+       // from `shift`, the layer's {scale, shift, mean, inv} rows of CO floats from `bias`), stores g, and with STATS leaves the
+       // per-column partial sums of g and g * xhat -- the whole bn_bwd_reduce pass of that layer
+       EPI_BNBWD_GATE6 = 6 };
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
 __host__ __device__ constexpr int stride16(int c) { return (c % 32 == 16) ? c : c + 16; }   // == 16 (mod 32)
@@ -362,6 +367,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
         ssum[c] = 0.f; ssq[c] = 0.f;
         if (EPI == EPI_BIAS_RELU6 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_BN_RELU6) bv = bias[n];
         if (EPI == EPI_BN_RELU6) sv = shift[n];
+        float gsc = 0.f, gsh = 0.f, gmean = 0.f, ginv = 0.f;
+        if (EPI == EPI_BNBWD_GATE6) { gsc = bias[n]; gsh = bias[CO + n]; gmean = bias[2 * CO + n]; ginv = bias[3 * CO + n]; }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -374,6 +381,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
                     if (EPI == EPI_BIAS) v = v + bv;
                     if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bv, 0.f);
                     if (EPI == EPI_BN_RELU6) v = relu6f(fmaf(v, bv, sv));
+                    if (EPI == EPI_BNBWD_GATE6) {
+                        const float zv = shift[m * CO + n], y = fmaf(zv, gsc, gsh);
+                        v = (y > 0.f && y < 6.f) ? v : 0.f;
+                        dst[m * CO + n] = v;
+                        if (STATS) { ssum[c] += v; ssq[c] = fmaf(v, (zv - gmean) * ginv, ssq[c]); }
+                        continue;
+                    }
                     dst[m * CO + n] = v;
                     if (STATS) { ssum[c] += v; ssq[c] = fmaf(v, v, ssq[c]); }
                 }

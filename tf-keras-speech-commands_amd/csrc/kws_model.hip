@@ -28,6 +28,23 @@ inline int same_pad_before(int n, int k, int s)
     return total / 2;   // TF 'SAME': the extra element goes to the end
 }
 
+// where in the step the caller's overlap event is recorded (and its callback runs): see kws_train_args.overlap_event
+struct OverlapHook {
+    hipEvent_t ev = nullptr;
+    void (*cb)(void *) = nullptr;
+    void *user = nullptr;
+    int at = 0;
+    bool fired = false;
+    int fire(int point, hipStream_t s)
+    {
+        if (fired || point != at) return KWS_OK;
+        fired = true;
+        if (ev) KWS_HIP_CHECK(hipEventRecord(ev, s));
+        if (cb) cb(user);
+        return KWS_OK;
+    }
+};
+
 #define KWS_TRY_NB(...)               \
     do {                              \
         const int rc__ = (__VA_ARGS__); \
@@ -272,7 +289,7 @@ int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], con
     // elsewhere (3 resident blocks per CU overlap their staging and MFMA phases better; measured per kernel at B = 4096)
     constexpr int RT = (MODE == MODE_FWD && CO == 128 && CR == 64) ? 3 : 2;
     const unsigned nblk = blocks_for(M, 32 * RT);
-    if (partial && (int)nblk <= kStatStride) {
+    if (partial && (int)nblk <= kStatStride && !src_planes) {
         KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, true>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, partial,
                    kStatStride);
         return (int)nblk;
@@ -280,6 +297,12 @@ int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], con
     if (src_planes) {                            // the A operand is already split (bn_bwd_apply_planes_kernel)
         if constexpr ((32 * RT * 4) % 256 == 0) {
             const Bf16Planes apl{{src_planes[0], src_planes[1], src_planes[2]}};
+            if constexpr (EPI == EPI_BNBWD_GATE6) {
+                if (!partial || (int)nblk > kStatStride) return fail(KWS_ERR_UNSUPPORTED, "fused BatchNorm-backward sums need at most %d blocks", kStatStride);
+                KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, true, true>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, partial,
+                           kStatStride, shift, apl);
+                return (int)nblk;
+            }
             KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, false, true>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, nullptr,
                        0, shift, apl);
             return 0;
@@ -334,8 +357,8 @@ constexpr int kPrepSplitBlocks = 16, kPrepZeroBlocks = 16, kPrepBlocks = 3 * kPr
 // zero_grads (training, split precision): the gradient buffer of the backward pass that follows is cleared on the side
 // stream beside the weight split instead of on the main chain; *zeroed tells the caller whether that happened
 int cnn_forward(const kws_model *m, const float *feat, int B, const float *params, float *state, CnnWs &w, bool training,
-                uint64_t seed, hipStream_t s, float *zero_grads = nullptr, bool *zeroed = nullptr, hipEvent_t overlap_event = nullptr,
-                void (*overlap_cb)(void *) = nullptr, void *overlap_user = nullptr, const double *moments = nullptr)
+                uint64_t seed, hipStream_t s, float *zero_grads = nullptr, bool *zeroed = nullptr, OverlapHook *hook = nullptr,
+                const double *moments = nullptr)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};   // conv input sizes
@@ -477,8 +500,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         const float rate = (training && l == 3 && seed != 0) ? 0.5f : 0.f;   // Dropout(0.5) after Flatten, cnn.py:63
         // behind the last convolution: from here to BN4's backward the main chain is small kernels (activation, dense, head),
         // the best place for the caller to start the next batch's featurizer (kws_train_args.overlap_event)
-        if (l == 3 && overlap_event) KWS_HIP_CHECK(hipEventRecord(overlap_event, s));
-        if (l == 3 && overlap_cb) overlap_cb(overlap_user);
+        if (l == 3 && hook) KWS_TRY(hook->fire(0, s));
         if (pool[l]) {
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
@@ -500,7 +522,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
 
 // ---- backward -----------------------------------------------------------------------------------------------
 int cnn_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
-                 hipEvent_t bucket_event, hipStream_t s, float *stats, bool grads_zeroed = false, const double *moments = nullptr)
+                 hipEvent_t bucket_event, hipStream_t s, float *stats, bool grads_zeroed = false, const double *moments = nullptr,
+                 OverlapHook *hook = nullptr)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
@@ -533,6 +556,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     {
         ConvGeom g;
         g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
+        if (hook) KWS_TRY(hook->fire(2, s));
         // its own fork, although every event costs the main chain 6-8 us: started later, together with conv4's weight
         // gradient, the step was 2 % slower (same-box A/B)
         if (int rc = fork(0)) return rc;
@@ -545,8 +569,11 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         }
         if (mprec == 1) KWS_TRY_NB(launch_bf16<128, 128, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.dd1, w.wsp[2], nullptr, w.da4, g, s));
         else KWS_TRY(launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s));
+        if (hook) KWS_TRY(hook->fire(3, s));
     }
+    int fused_bn3_blocks = 0;          // > 0: conv4's data gradient already did layer 3's BatchNorm-backward reduction
     for (int l = 3; l >= 1; --l) {
+        if (hook && l == 2) KWS_TRY(hook->fire(5, s));
         const int C = kCh[l + 1];
         const long M = (long)B * Hz[l] * Wz[l];
         const float *da = l == 3 ? w.da4 : w.da[l];
@@ -569,7 +596,9 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             else
                 KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_pool_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l],
                            const_cast<float *>(da), k, w.gz[l], B, Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);
-        } else
+        } else if (l == 2 && fused_bn3_blocks > 0)
+            nblk = fused_bn3_blocks;
+        else
             KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
                        rows, w.partial, rate, slo, shi);
         KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
@@ -589,6 +618,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         const float *in = w.a[l - 1];
         float *dk = grads + m->o_k[l];
         const float *kern = params + m->o_k[l];
+        if (hook && l == 3) KWS_TRY(hook->fire(4, s));
         if (l != 1)
             if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
@@ -602,7 +632,15 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                 // not wait for the conv4 wgrad.
                 KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
             }
-            if (mprec == 1) KWS_TRY_NB(launch_bf16<128, 64, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", nullptr, w.wsp[1], nullptr, w.da[2], g, s, nullptr, nullptr, w.dzp));
+            if (mprec == 1 && blocks_for((long)B * Hs[3] * Ws[3], 64) <= (unsigned)kStatStride) {
+                // the data gradient's epilogue is BatchNorm 3's backward reduction (conv3 has no pooling): it gates by ReLU6(y3), stores
+                // g in gz[2] and leaves the partial sums of g and g xhat -- no bn_bwd_reduce pass over (z3, da3)
+                const BnCoef k3 = coef_of(w.coef[2], 64);
+                fused_bn3_blocks = launch_bf16<128, 64, MODE_DGRAD, EPI_BNBWD_GATE6>("conv_bf16_dgrad", nullptr, w.wsp[1], k3.scale, w.gz[2], g, s, w.partial,
+                                                                                   w.z[2], w.dzp);
+                if (fused_bn3_blocks < 0) return fused_bn3_blocks;
+            } else if (mprec == 1)
+                KWS_TRY_NB(launch_bf16<128, 64, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", nullptr, w.wsp[1], nullptr, w.da[2], g, s, nullptr, nullptr, w.dzp));
             else KWS_TRY(launch_dgrad<128, 64, 1>(w.gz[3], kern, w.da[2], g, s));
         } else if (l == 2) {
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
@@ -1173,12 +1211,16 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool lite = m->kind == KWS_SIMPLE_CNN_LITE;
     bool grads_zeroed = false;     // cleared beside the weight split (the main chain joins that branch before conv3)
+    // point 0 = behind the last forward convolution (simple_cnn); swept again with the persistent featurizer (same box, ms/step):
+    // 0: 0.722, behind the loss 0.753, behind the head's backward 0.721, behind the dense data gradient 0.734, behind BN4's
+    // backward 0.760, behind conv4's data gradient 0.727
+    OverlapHook hook;
+    hook.ev = static_cast<hipEvent_t>(a->overlap_event); hook.cb = a->overlap_callback; hook.user = a->overlap_user;
+    hook.at = lite ? 1 : 0;
     rc = lite ? lite_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s)
-              : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s, a->grads, &grads_zeroed,
-                            static_cast<hipEvent_t>(a->overlap_event), a->overlap_callback, a->overlap_user, a->feat_moments);
+              : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s, a->grads, &grads_zeroed, &hook, a->feat_moments);
     if (rc) return rc;
-    if (lite && a->overlap_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->overlap_event), s));
-    if (lite && a->overlap_callback) a->overlap_callback(a->overlap_user);
+    if (lite) KWS_TRY(hook.fire(1, s));
     // Keras reduces the per-sample losses with a batch mean (train.py:75-77): d(mean)/d(logits) carries 1/B
     // simple_cnn: the head's backward kernel also sums the per-sample losses (no separate loss_reduce launch)
     const bool fuse_stats = !lite && head_bwd_fuses(m);
@@ -1186,9 +1228,10 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
                   a->grad_scale / (float)a->B, fuse_stats ? nullptr : a->stats, a->ignore_index, s);
     if (rc) return rc;
     if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
+    if (!lite) KWS_TRY(hook.fire(1, s));
     return lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
                 : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s,
-                               fuse_stats ? a->stats : nullptr, grads_zeroed, a->feat_moments);
+                               fuse_stats ? a->stats : nullptr, grads_zeroed, a->feat_moments, &hook);
 }
 
 int kws_set_matrix_precision(int mode)

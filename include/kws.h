@@ -169,6 +169,15 @@ int64_t kws_model_workspace_bytes(const kws_model *m, int B, int training);
 int kws_model_forward(kws_model *m, const float *feat, int B, const float *params, const float *state, void *ws,
                       size_t ws_bytes, float *probs, int32_t *argmax, void *stream);
 
+/* Inference with FIXED weights (serving, evaluation): kws_model_prepare_inference derives everything kws_model_forward computes
+ * from the weights alone -- the folded BatchNormalization coefficients, the bf16 planes of the split-precision matrix operands,
+ * the fp16 weight blob of simple_cnn_lite -- once, into `ws`; every later kws_model_forward with the SAME (B, params, state, ws)
+ * and precisions then skips that work (17 of 300 us per call at B = 4096 for simple_cnn).  The caller promises not to change
+ * `params` / `state` in between; kws_model_invalidate_prepared (or a train step, a different forward in the same workspace,
+ * kws_model_set_precision) drops the prepared state.  Recurrent models have nothing to prepare (returns KWS_OK). */
+int kws_model_prepare_inference(kws_model *m, int B, const float *params, const float *state, void *ws, size_t ws_bytes, void *stream);
+int kws_model_invalidate_prepared(kws_model *m);
+
 /* One training forward + backward (what Keras does per batch inside model.fit, train.py:81):
  * batch-statistics BN (moving stats in `state` are updated), dropout from `dropout_seed` (0 = off),
  * loss = classifier/loss.py SparseCategoricalCrossEntropy (class_weights NULL) or

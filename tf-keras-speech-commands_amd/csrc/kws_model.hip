@@ -67,12 +67,14 @@ struct CnnWs {
     __bf16 *dzp[3];     // simple_cnn training: h/m/l planes of dz4 (written by BN4's backward, read by conv4's data / weight gradients)
     double *partial;    // [kMaxStatBlocks][2][256]
     double *moments;    // Q[10][10] of the feature map (kws_layer1_moments.h) when the caller did not supply it
+    unsigned char *base;
     size_t bytes;
 };
 
 CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
 {
     CnnWs w{};
+    w.base = base;
     size_t off = 0;
     auto take = [&](size_t nfloats) {
         float *p = reinterpret_cast<float *>(base + off);
@@ -275,6 +277,9 @@ int launch_dgrad(const float *dz, const float *w, float *dx, const ConvGeom &g, 
 // split, fp32-level error); 0: every product on the fp32 MFMA.  kws_set_matrix_precision() switches it library-wide.
 static int g_matrix_precision = 1;
 static inline int matrix_prec(const kws_model *m) { return m->matrix_precision >= 0 ? m->matrix_precision : g_matrix_precision; }
+// Storage / matrix-operand precision of simple_cnn_lite INFERENCE (kws_set_inference_precision): 0 = fp32, 1 = fp16
+static int g_infer_precision = 0;
+static inline int infer_prec(const kws_model *m) { return m->infer_precision >= 0 ? m->infer_precision : g_infer_precision; }
 
 // returns the number of blocks that wrote BatchNorm partial sums (0: `partial` was not given or the grid exceeds its stride)
 template <int CR, int CO, int MODE, int EPI>
@@ -367,6 +372,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
 
     const bool bf16 = matrix_prec(m) == 1;
+    // inference after kws_model_prepare_inference on the same buffers: the weight planes and BatchNorm coefficients are in place
+    const bool prepared = !training && m->prepared_for(params, state, w.base, B, matrix_prec(m), infer_prec(m));
     ModelRes *R = nullptr;       // only the split-on-the-side-stream branch below needs the model's stream / events
     // training in split precision at a geometry the MFMA layer-1 kernels cover: the weight split and the gradient clear ride
     // in the grid of the layer-1 activation kernel -- no side-stream branch, no events
@@ -390,9 +397,10 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     } else if (bf16) {
         // inference stays on ONE stream: callers capture it into hipGraphs, and a fork to the library's side stream inside
         // several captured graphs made every graph after the first replay 0.2 ms slower
-        if (int rc = split_weights(m, params, w, s)) return rc;
+        if (!prepared)
+            if (int rc = split_weights(m, params, w, s)) return rc;
     }
-    if (!training)
+    if (!training && !prepared)
         if (int rc = infer_coefs(m, params, state, w, s)) return rc;
     // layer 1: conv1 is recomputed from the feature map wherever z1 is needed (kws_layer1.h)
     {
@@ -743,8 +751,6 @@ ConvGeom geom1x1(int B, int H, int W)
 }
 
 // Storage / matrix-operand precision of simple_cnn_lite INFERENCE (kws_set_inference_precision): 0 = fp32, 1 = fp16
-static int g_infer_precision = 0;
-static inline int infer_prec(const kws_model *m) { return m->infer_precision >= 0 ? m->infer_precision : g_infer_precision; }
 
 // fp16 inference (kws_lite_f16.h): front kernel with fp16 output, then ONE kernel from a2 to the probabilities.
 // The fp16 weight blob lives at the head of the (otherwise unused in inference) double partial slab.
@@ -756,10 +762,13 @@ static int lite_forward_f16(const kws_model *m, const float *feat, int B, const 
     if (!front_ok || d.H2 * d.W2 > kF16MaxN2 || d.H3 * d.W3 > kF16MaxP3 || d.H4 < 1 || d.W4 < 1 || m->C > kF16HeadCols || d.flat > kWdRow)
         return fail(KWS_ERR_UNSUPPORTED, "fp16 inference of simple_cnn_lite needs a feature map up to about 30 x 20 and at most %d classes "
                                          "(got %d x %d, %d classes): use KWS_INFER_FP32", kF16HeadCols, d.H0, d.W0, m->C);
-    if (int rc = infer_coefs(m, params, state, w, s)) return rc;
+    const bool prepared = m->prepared_for(params, state, w.base, B, matrix_prec(m), infer_prec(m));
     _Float16 *blob = reinterpret_cast<_Float16 *>(w.partial);
-    KWS_LAUNCH("lite_f16_prepare_kernel", lite_f16_prepare_kernel, dim3(32), dim3(256), 0, s, params + m->o_pwk[2], params + m->o_pwk[3],
-               params + m->o_dk, params + m->o_hk, m->C, d.flat, blob);
+    if (!prepared) {
+        if (int rc = infer_coefs(m, params, state, w, s)) return rc;
+        KWS_LAUNCH("lite_f16_prepare_kernel", lite_f16_prepare_kernel, dim3(32), dim3(256), 0, s, params + m->o_pwk[2], params + m->o_pwk[3],
+                   params + m->o_dk, params + m->o_hk, m->C, d.flat, blob);
+    }
     BnCoef k0 = coef_of(w.coef[0], 16), k1 = coef_of(w.coef[1], 32), k2 = coef_of(w.coef[2], 64), k3 = coef_of(w.coef[3], 128);
     const LiteFrontArgs fa = {params + m->o_dwk[0], params + m->o_pwk[0], params + m->o_pwb[0], k0.scale, k0.shift,
                               params + m->o_dwk[1], params + m->o_pwk[1], params + m->o_pwb[1], k1.scale, k1.shift};
@@ -795,7 +804,7 @@ int lite_forward(const kws_model *m, const float *feat, int B, const float *para
     const bool pool[4] = {true, true, false, true};
     const uint32_t slo = (uint32_t)(seed & 0xFFFFFFFFu), shi = (uint32_t)(seed >> 32);
     int l_begin = 0;
-    if (!training)
+    if (!training && !m->prepared_for(params, state, w.base, B, matrix_prec(m), infer_prec(m)))
         if (int rc = infer_coefs(m, params, state, w, s)) return rc;
     if (!training && d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * 12 && d.H2 >= 1 && d.W2 >= 1) {
         // inference: stages 1 and 2 fused, one wave per clip, features -> a2 without touching HBM in between (kws_lite.h)
@@ -1060,6 +1069,33 @@ int kws_feature_moments(const float *feat, int B, int n_features, int feature_si
     return KWS_OK;
 }
 
+int kws_model_prepare_inference(kws_model *m, int B, const float *params, const float *state, void *ws, size_t ws_bytes, void *stream)
+{
+    if (!m || !params || !state) return fail(KWS_ERR_INVALID, "null argument");
+    if (B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
+    m->prep = kws_model::Prepared{};
+    if (m->kind == KWS_SIMPLE_GRU || m->kind == KWS_SIMPLE_LSTM) return KWS_OK;      // nothing derived from the weights
+    CnnWs w;
+    if (int rc = check_ws(m, B, false, ws, ws_bytes, w)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    KWS_TRY(infer_coefs(m, params, state, w, s));
+    if (m->kind == KWS_SIMPLE_CNN && matrix_prec(m) == 1) KWS_TRY(split_weights(m, params, w, s));
+    if (m->kind == KWS_SIMPLE_CNN_LITE && infer_prec(m) == KWS_INFER_FP16)
+        KWS_LAUNCH("lite_f16_prepare_kernel", lite_f16_prepare_kernel, dim3(32), dim3(256), 0, s, params + m->o_pwk[2], params + m->o_pwk[3],
+                   params + m->o_dk, params + m->o_hk, m->C, m->d.flat, reinterpret_cast<_Float16 *>(w.partial));
+    KWS_LAUNCH_CHECK("inference preparation");
+    m->prep.params = params; m->prep.state = state; m->prep.ws = ws; m->prep.B = B;
+    m->prep.matrix = matrix_prec(m); m->prep.infer = infer_prec(m);
+    return KWS_OK;
+}
+
+int kws_model_invalidate_prepared(kws_model *m)
+{
+    if (!m) return fail(KWS_ERR_INVALID, "null argument");
+    m->prep = kws_model::Prepared{};
+    return KWS_OK;
+}
+
 int kws_model_set_precision(kws_model *m, int matrix, int infer)
 {
     if (!m) return fail(KWS_ERR_INVALID, "null argument");
@@ -1067,6 +1103,7 @@ int kws_model_set_precision(kws_model *m, int matrix, int infer)
     if (infer != -1 && infer != KWS_INFER_FP32 && infer != KWS_INFER_FP16) return fail(KWS_ERR_INVALID, "unknown inference precision %d", infer);
     m->matrix_precision = matrix;
     m->infer_precision = infer;
+    m->prep = kws_model::Prepared{};
     return KWS_OK;
 }
 
@@ -1192,6 +1229,8 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
     int rc = check_ws(m, B, false, ws, ws_bytes, w);
     if (rc) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // a forward that is not the prepared one re-derives the tables in this workspace: whatever was prepared in it is gone
+    if (m->prep.ws == ws && !m->prepared_for(params, state, ws, B, matrix_prec(m), infer_prec(m))) m->prep = kws_model::Prepared{};
     if (m->kind == KWS_SIMPLE_CNN_LITE && infer_prec(m) == KWS_INFER_FP16)
         return lite_forward_f16(m, feat, B, params, state, w, probs, argmax, s);
     rc = m->kind == KWS_SIMPLE_CNN_LITE ? lite_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s)
@@ -1208,6 +1247,7 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     CnnWs w;
     int rc = check_ws(m, a->B, true, a->ws, a->ws_bytes, w);
     if (rc) return rc;
+    m->prep = kws_model::Prepared{};       // a train step rewrites the BatchNorm coefficients (and is followed by a weight update)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool lite = m->kind == KWS_SIMPLE_CNN_LITE;
     bool grads_zeroed = false;     // cleared beside the weight split (the main chain joins that branch before conv3)

@@ -50,6 +50,13 @@ struct kws_model {
     // -1: follow the library-wide default (kws_set_matrix_precision / kws_set_inference_precision); else the model's own
     int matrix_precision = -1, infer_precision = -1;
     int deterministic = 0;       // 1: weight gradients reduced in a fixed order (kws_model_set_deterministic)
+    // kws_model_prepare_inference: the weight-derived tables of an inference forward (bf16 weight planes, folded BatchNorm
+    // coefficients, fp16 weight blob) already sit in THIS workspace for THESE buffers, batch and precisions
+    struct Prepared { const float *params = nullptr, *state = nullptr; void *ws = nullptr; int B = 0, matrix = -2, infer = -2; } prep;
+    bool prepared_for(const float *p, const float *st, void *w, int B, int matrix, int infer) const
+    {
+        return prep.params == p && prep.state == st && prep.ws == w && prep.B == B && prep.matrix == matrix && prep.infer == infer && p != nullptr;
+    }
     std::mutex res_mu;
     std::map<int, kws::ModelRes> res;   // per device, created on first use
     kws::ModelRes *dev_res();           // resources for the CURRENT device (nullptr on failure)

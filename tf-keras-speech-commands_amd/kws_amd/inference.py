@@ -25,7 +25,9 @@ class InferenceSession(object):
         self.features = torch.empty((self.batch, g["n_features"], g["feature_size"]), dtype=torch.float32, device=dev)
         self.probs = self.argmax = None
         self._graph = None
+        self._ws = device_model.new_workspace(self.batch)          # private: the prepared weight tables live in it
         self._eager()                                   # warm-up: allocations (workspace, outputs) happen outside the capture
+        self.refresh()                                  # weights are fixed from here on: derive their tables once, not per batch
         torch.cuda.synchronize()
         if use_graph:
             graph = torch.cuda.CUDAGraph()
@@ -33,9 +35,14 @@ class InferenceSession(object):
                 self._eager()
             self._graph = graph
 
+    def refresh(self):
+        """Call after the model's weights changed (set_weights / training): re-derives the weight tables the captured forward
+        reads (kws_model_prepare_inference); the graph itself stays valid, its kernels read the same buffers."""
+        self.dm.prepare_inference(self.batch, workspace=self._ws)
+
     def _eager(self):
         self.feat(self.wav, out=self.features)
-        self.probs, self.argmax = self.dm.forward(self.features)
+        self.probs, self.argmax = self.dm.forward(self.features, workspace=self._ws)
 
     def run(self):
         if self._graph is not None:

@@ -89,6 +89,8 @@ def get_lib():
     L.kws_model_workspace_bytes.restype = i64
     L.kws_model_forward.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, vp]
     L.kws_model_train_fwd_bwd.argtypes = [vp, ctypes.POINTER(KwsTrainArgs), vp]
+    L.kws_model_prepare_inference.argtypes = [vp, i32, vp, vp, vp, ctypes.c_size_t, vp]
+    L.kws_model_invalidate_prepared.argtypes = [vp]
     L.kws_feature_moments_workspace_bytes.argtypes = [i32]
     L.kws_feature_moments_workspace_bytes.restype = i64
     L.kws_feature_moments.argtypes = [vp, i32, i32, i32, vp, vp, ctypes.c_size_t, vp]

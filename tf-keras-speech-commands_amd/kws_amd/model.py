@@ -118,6 +118,7 @@ class DeviceModel(object):
             (p if t["trainable"] else s)[t["offset"]:t["offset"] + t["size"]] = w.reshape(-1)
         self.params.copy_(torch.from_numpy(p))
         self.state.copy_(torch.from_numpy(s))
+        self.invalidate_prepared()
 
     def _split(self, flat_trainable, flat_state):
         out = []
@@ -156,8 +157,22 @@ class DeviceModel(object):
         _l.check(self._L.kws_model_set_deterministic(self.spec.handle, 1 if on else 0))
 
     # ---- compute ---------------------------------------------------------------------------------------------
-    def _workspace(self, batch, training):
+    def new_workspace(self, batch, training=False):
+        """a private workspace tensor for `batch` (InferenceSession keeps one, so that the tables prepared in it are not shared
+        with any other caller of this model)"""
         torch = _torch()
+        return torch.empty((self.spec.workspace_bytes(batch, training) + 256,), dtype=torch.uint8, device=self.device)
+
+    @staticmethod
+    def _aligned(buf):
+        base = buf.data_ptr()
+        aligned = (base + 255) & ~255
+        return aligned, buf.numel() - (aligned - base)
+
+    def _workspace(self, batch, training, workspace=None):
+        torch = _torch()
+        if workspace is not None:
+            return self._aligned(workspace)
         need = self.spec.workspace_bytes(batch, training)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need + 256,), dtype=torch.uint8, device=self.device)
@@ -173,10 +188,22 @@ class DeviceModel(object):
                              % (self.spec.n_features, self.spec.feature_size))
         return feat.numel() // n
 
-    def forward(self, feat, want_probs=True, want_argmax=True):
+    def prepare_inference(self, batch, workspace=None):
+        """kws_model_prepare_inference for `batch` clips: later forward() calls of that batch size skip the weight-derived work
+        until the weights change (set_weights and the optimizer steps of this object drop the prepared state; whoever writes
+        self.params / self.state directly must call invalidate_prepared())."""
+        torch = _torch()
+        ws, nbytes = self._workspace(int(batch), False, workspace)
+        _l.check(self._L.kws_model_prepare_inference(self.spec.handle, int(batch), self.params.data_ptr(), self.state.data_ptr(), ws, nbytes,
+                                                     torch.cuda.current_stream().cuda_stream))
+
+    def invalidate_prepared(self):
+        _l.check(self._L.kws_model_invalidate_prepared(self.spec.handle))
+
+    def forward(self, feat, want_probs=True, want_argmax=True, workspace=None):
         torch = _torch()
         B = self._check_feat(feat)
-        ws, nbytes = self._workspace(B, False)
+        ws, nbytes = self._workspace(B, False, workspace)
         probs = torch.empty((B, self.spec.num_classes), dtype=torch.float32, device=self.device) if want_probs else None
         am = torch.empty((B,), dtype=torch.int32, device=self.device) if want_argmax else None
         _l.check(self._L.kws_model_forward(self.spec.handle, feat.data_ptr(), B, self.params.data_ptr(), self.state.data_ptr(),
@@ -237,6 +264,7 @@ class DeviceModel(object):
     def adam_step(self, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
         torch = _torch()
         self.step_count += 1
+        self.invalidate_prepared()
         _l.check(self._L.kws_adam_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                                        self.adam_v.data_ptr(), self.params.numel(), float(lr), float(beta1), float(beta2),
                                        float(eps), self.step_count, float(grad_scale), torch.cuda.current_stream().cuda_stream))
@@ -244,12 +272,14 @@ class DeviceModel(object):
     def sgd_step(self, lr, grad_scale=1.0):
         torch = _torch()
         self.step_count += 1
+        self.invalidate_prepared()
         _l.check(self._L.kws_sgd_step(self.params.data_ptr(), self.grads.data_ptr(), self.params.numel(), float(lr),
                                       float(grad_scale), torch.cuda.current_stream().cuda_stream))
 
     def rmsprop_step(self, lr, rho=0.9, eps=1e-7, grad_scale=1.0):
         torch = _torch()
         self.step_count += 1
+        self.invalidate_prepared()
         _l.check(self._L.kws_rmsprop_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_v.data_ptr(),
                                           self.params.numel(), float(lr), float(rho), float(eps), float(grad_scale),
                                           torch.cuda.current_stream().cuda_stream))

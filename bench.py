@@ -22,6 +22,12 @@ import os
 import sys
 import time
 
+# HIP deals streams to hardware queues (default 4 per device).  The step runs on three streams (caller's, the model's side
+# stream, the feature pipeline's); with an RCCL communicator alive in the process the default dealt them so that the step's
+# fork/join branches serialised (1.2 ms/step instead of 0.72, measured).  Two queues give the same step
+# time with and without a communicator.  Must be in the environment before the first HIP call; a caller's own setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "tf-keras-speech-commands_amd")
 for _p in (ROOT, PKG):
@@ -380,20 +386,21 @@ def main():
     wav_np, lab_np = synthetic_batch(B, rank, N_CLASSES)
     wav = torch.from_numpy(wav_np).cuda()
     labels = torch.from_numpy(lab_np).cuda()
-    # data path collective: the C ABI's RCCL communicator (csrc/kws_comm.hip), bootstrapped over the torch group
-    comm = None
-    if world > 1:
-        comm = KwsComm.from_torch_group()
-    elif args.force_comm:
-        comm = KwsComm.single()
     split = dm.grad_split
     from kws_amd.pipeline import FeaturePipeline
     # the pipeline's featurizer shares the chip with the train step (half of each CU's LDS, FeaturePipeline sets it), so it is
     # its own object: feat_fn keeps the whole chip for the stand-alone workloads under `extra`
     pipe = FeaturePipeline(Featurizer(pr), B, pr.n_features, pr.feature_size, moments=True)   # + kws_feature_moments behind the featurizer
+    # data path collective: the C ABI's RCCL communicator (csrc/kws_comm.hip), bootstrapped over the torch group's store.  Created
+    # AFTER the model (whose side stream exists since DeviceModel()) and the pipeline's stream: HIP deals streams to hardware queues
+    # in creation order and RCCL creates its own (include/kws.h: kws_model_bind_device)
+    comm = None
+    if world > 1:
+        comm = KwsComm.from_torch_group()
+    elif args.force_comm:
+        comm = KwsComm.from_torch_group() if dist is not None else KwsComm.single()      # a one-rank world runs the same code
     step_no = [0]
     overlap_ev = torch.cuda.Event()
-    bucket_ev = torch.cuda.Event() if comm is not None else None
 
     def submit_next():
         pipe.submit(wav, after=overlap_ev)
@@ -410,14 +417,13 @@ def main():
             feat, mom = pipe.take()
             # next batch's features on the side stream, started behind this step's last forward convolution: the library
             # records overlap_ev there and calls back, so the featurizer launch also sits at that point in HOST order
+            # data parallel: the step exchanges its gradients itself (kws_train_args.comm): the early bucket (conv4 + dense + head,
+            # 82 % of the bytes) on the model's side stream right behind conv4's weight gradient, the late bucket + BatchNormalization
+            # statistics behind the backward pass on this stream; Adam follows in stream order
             dm.train_fwd_bwd(feat, labels, dropout_seed=step_no[0], grad_scale=1.0 / world, overlap_event=overlap_ev,
-                             overlap_callback=submit_next if i + 1 < n else None, bucket_event=bucket_ev, feat_moments=mom)
+                             overlap_callback=submit_next if i + 1 < n else None, feat_moments=mom, comm=comm, comm_state_weight=1.0 / world)
             # no pipe.release() here: the featurizer that rewrites this step's feature buffer (batch k+2) is ordered behind the NEXT
             # step's overlap event on this stream, i.e. behind every kernel of this step
-            if comm is not None:
-                # early bucket (conv4 + dense + head, 82 % of the bytes) on the communicator's stream as soon as the library's
-                # bucket event fires, late bucket + BatchNormalization statistics behind the backward pass; Adam waits for both
-                comm.allreduce_grads(dm.grads, split, bucket_ev, dm.state, 1.0 / world)
             dm.adam_step(1e-3)
 
     def fence():
@@ -466,7 +472,7 @@ def main():
             allreduce_us = {"early_bucket": round(float(np.mean([a[0] for a in ar if a[0] is not None] or [0.0])), 2),
                             "late_bucket_with_bn_statistics": round(float(np.mean([a[1] for a in ar if a[1] is not None] or [0.0])), 2),
                             "early_bucket_floats": int(dm.params.numel() - split), "late_bucket_floats": int(split),
-                            "how": "HIP events on the communicator's stream around each RCCL launch, mean over %d serial steps on rank 0" % len(ar)}
+                            "how": "HIP events around each RCCL launch on the stream it is enqueued on, mean over %d serial steps on rank 0" % len(ar)}
         if rank == 0:
             rep_serial = L.prof_report()
             L.prof_enable(False)
@@ -580,8 +586,8 @@ def main():
                                               "with fp32 accumulation (fp32-level error, kws_model_set_precision); conv1, conv3 "
                                               "data gradient, dense weight gradient and everything else fp32; extra.fp32_mfma_step is the all-fp32 number",
                           "input_pipeline": "features of batch k+1 (and their second moments for layer 1, kws_feature_moments) computed on a side stream during step k, started behind the last forward convolution (kws_train_args.overlap_event; all K featurizations inside the timed region)",
-                          "gradient_exchange": ("kws_allreduce_grads (RCCL behind the C ABI): early bucket grads[%d:] on the communicator's stream behind the library's bucket event, "
-                                                "late bucket + BN moving statistics grouped behind the backward pass, Adam waits for both" % split) if comm is not None else "none (one rank)",
+                          "gradient_exchange": ("kws_train_args.comm (RCCL behind the C ABI): early bucket grads[%d:] on the model's side stream behind conv4's weight gradient, "
+                                                "late bucket + BN moving statistics grouped on the main stream behind the backward pass" % split) if comm is not None else "none (one rank)",
                           "allreduce_us": allreduce_us,
                           "train_step_hbm_roofline_frac": round(value / world * 229.8e3 / (HBM_PEAK_GBS * 1e9), 4),
                           "library_build": L.build_id().get("kws_featurize.hip")},

@@ -161,6 +161,11 @@ int64_t kws_model_param_count(const kws_model *m);
 int64_t kws_model_state_count(const kws_model *m);
 int kws_model_num_tensors(const kws_model *m);
 int kws_model_tensor_info(const kws_model *m, int index, kws_tensor_info *out);
+/* Creates the model's per-device resources (its side stream and fork / join events) on the CURRENT device now instead of at the first
+ * train step.  HIP deals streams to a small number of hardware queues in creation order; when the side stream lands on the queue of
+ * the caller's stream the step's fork / join overlap is lost (measured: 0.65 -> 1.2 ms per step when an RCCL communicator, which
+ * creates streams of its own, was initialised before the model's first step).  Call it before kws_comm_init. */
+int kws_model_bind_device(kws_model *m);
 /* bytes of 256-byte aligned device scratch the calls below need for batch B */
 int64_t kws_model_workspace_bytes(const kws_model *m, int B, int training);
 
@@ -183,6 +188,7 @@ int kws_model_invalidate_prepared(kws_model *m);
  * loss = classifier/loss.py SparseCategoricalCrossEntropy (class_weights NULL) or
  * WeightedSparseCategoricalCrossEntropy (class_weights: C device floats), reduced by the batch mean.
  * grads <- grad_scale * d(mean loss)/d(params)  (data parallel: grad_scale = 1/world, then sum-all-reduce). */
+struct kws_comm;
 typedef struct kws_train_args {
     const float *feat;          /* (B, n_features, feature_size)                                   */
     const int32_t *labels;      /* (B) class indices                                               */
@@ -216,6 +222,14 @@ typedef struct kws_train_args {
                                    puts that launch at the same place in HOST order, so the overlap does not depend on how far
                                    the host runs ahead of the device (under a tracing profiler it does not run ahead at all) */
     void *overlap_user;
+    struct kws_comm *comm;      /* NULL, or a communicator (kws_comm_init): the step then EXCHANGES its gradients itself -- sum over the
+                                   ranks, in place: the early bucket grads[kws_model_grad_split(m), P) (conv4 + BN4 + dense + head, 82 % of
+                                   the bytes, final first) on the model's side stream right behind conv4's weight gradient, i.e. under the
+                                   rest of the backward pass; the late bucket together with `state * comm_state_weight` (BatchNormalization
+                                   moving statistics: weight = local clips / global clips gives their batch-weighted mean over the replicas)
+                                   on `stream` behind the backward pass.  When the call returns, kws_adam_step can be enqueued on `stream`.
+                                   Set grad_scale = local clips / global clips.  bucket_event is not needed (and still honoured).        */
+    float comm_state_weight;
     const double *feat_moments; /* NULL or the KWS_FEATURE_MOMENTS doubles kws_feature_moments() wrote for `feat` (same B): simple_cnn
                                    derives the batch statistics of its first BatchNormalization and the closed forms of its first
                                    layer's gradients from them instead of computing them at the head of the step, so an input
@@ -279,9 +293,11 @@ int64_t kws_model_grad_split(const kws_model *m);
  *
  *   rank 0:  kws_comm_unique_id(id);  ship the 128 bytes to every rank (file, socket, MPI, torch.distributed ...)
  *   all:     kws_comm_init(rank, world, id, &comm)            -- collective
- *   step:    kws_model_train_fwd_bwd(..., bucket_event ...);  grad_scale = local clips / global clips
- *            kws_allreduce_grads(comm, grads, P, kws_model_grad_split(m), bucket_event, state, S, weight, stream);
+ *   step:    args.comm = comm; args.grad_scale = args.comm_state_weight = local clips / global clips;
+ *            kws_model_train_fwd_bwd(m, &args, stream);       -- gradients arrive summed over the ranks
  *            kws_adam_step(...)
+ * The communicator owns no stream: every collective is enqueued on a stream the step already uses (a collective on a stream of its
+ * own stalled the device by ~1.1 ms per step on MI355X / ROCm 7.2: 0.65 -> 1.79 ms, tools/commbench.py).
  * ---------------------------------------------------------------------- */
 typedef struct kws_comm kws_comm;
 #define KWS_COMM_ID_BYTES 128
@@ -291,25 +307,20 @@ void kws_comm_destroy(kws_comm *c);
 /* rccl_version: NCCL-style code of the bound library (e.g. 22707), 0 if unknown; any out pointer may be NULL */
 int kws_comm_info(const kws_comm *c, int *rank, int *world, int *rccl_version);
 
-/* In-place sum over ranks of the flat gradient buffer `grads` (n floats), as two buckets on the communicator's own
- * high-priority stream:
- *   early  grads[split, n)  starts as soon as `bucket_event` (kws_train_args.bucket_event of the step just enqueued) fires,
- *                           i.e. while the rest of the backward pass still runs on `stream`;
- *   late   grads[0, split)  behind everything enqueued on `stream` so far, grouped with the sum of
- *          state[0, n_state) * state_weight  (BatchNormalization moving statistics: weight = local clips / global clips
- *                           gives their batch-weighted mean over the replicas; n_state = 0 skips it).
- * `stream` then waits for the communicator's stream, so the optimizer step may be enqueued on it right away.
- * bucket_event == NULL or split in {0, n}: one bucket, no overlap.  world == 1 runs the same code path. */
-int kws_allreduce_grads(kws_comm *c, float *grads, int64_t n, int64_t split, void *bucket_event, float *state, int64_t n_state,
-                        float state_weight, void *stream);
+/* The exchange as a call of its own, for steps that did not run kws_model_train_fwd_bwd with args.comm (a rank whose shard of a
+ * partial last batch is empty: cleared gradients, weight 0; or a caller with its own backward pass): in-place sum over the ranks of
+ * grads[split, n), then -- one RCCL group -- of grads[0, split) and of state[0, n_state) * state_weight, all on `stream`, i.e.
+ * the same collectives in the same order as the train step issues, so ranks may mix the two forms.  split in {0, n}: one bucket. */
+int kws_allreduce_grads(kws_comm *c, float *grads, int64_t n, int64_t split, float *state, int64_t n_state, float state_weight,
+                        void *stream);
 
-/* A plain in-place all-reduce ordered with `stream` on both sides (loss / hit counters of a logging step, timing maxima). */
+/* A plain in-place all-reduce on `stream` (loss / hit counters of a logging step, timing maxima). */
 enum { KWS_DT_F32 = 0, KWS_DT_F64 = 1, KWS_DT_I32 = 2, KWS_DT_I64 = 3 };
 enum { KWS_OP_SUM = 0, KWS_OP_MAX = 1, KWS_OP_AVG = 2 };
 int kws_comm_allreduce(kws_comm *c, void *buf, int64_t n, int dtype, int op, void *stream);
 
-/* Opt-in timing of the two buckets of the most recent kws_allreduce_grads (HIP events on the communicator's stream);
- * kws_comm_last_us synchronises those events; -1 = that bucket was not issued / timing off. */
+/* Opt-in timing of the two buckets of the most recent exchange (HIP events around each RCCL launch on the stream it was enqueued
+ * on); kws_comm_last_us synchronises those events; -1 = that bucket was not issued / timing off. */
 int kws_comm_timing(kws_comm *c, int on);
 int kws_comm_last_us(kws_comm *c, float *early_us, float *late_us);
 

@@ -221,17 +221,30 @@ class KWSModel(object):
         zeros.  The BatchNormalization moving statistics are averaged with the same weights in the same exchange."""
         import torch
         if dp is not None and dp.active:
-            ev = self._bucket_event
             weight = dp.grad_scale if weight is None else weight
-            if xb.shape[0] > 0:
-                dm.train_fwd_bwd(self._features_of(xb, is_audio), yb, cw, dropout_seed=seed, grad_scale=weight, ignore_index=ignore_index,
-                                 bucket_event=ev)
-                stats = dm.stats
+            state = dm.state if self.spec.state_count > 0 else None
+            if dp.comm is not None:
+                # the step exchanges its gradients itself (kws_train_args.comm: early bucket under the rest of the backward pass); a rank
+                # without clips joins the same collectives with cleared gradients and weight 0
+                if xb.shape[0] > 0:
+                    dm.train_fwd_bwd(self._features_of(xb, is_audio), yb, cw, dropout_seed=seed, grad_scale=weight, ignore_index=ignore_index,
+                                     comm=dp.comm, comm_state_weight=weight)
+                    stats = dm.stats
+                else:
+                    dm.grads.zero_()
+                    stats = torch.zeros_like(dm.stats)
+                    dp.comm.allreduce_grads(dm.grads, dm.grad_split, state, weight)
             else:
-                dm.grads.zero_()
-                ev.record()
-                stats = torch.zeros_like(dm.stats)
-            dp.sync_grads(dm.grads, dm.grad_split, ev, state=dm.state if self.spec.state_count > 0 else None, state_weight=weight)
+                ev = self._bucket_event
+                if xb.shape[0] > 0:
+                    dm.train_fwd_bwd(self._features_of(xb, is_audio), yb, cw, dropout_seed=seed, grad_scale=weight, ignore_index=ignore_index,
+                                     bucket_event=ev)
+                    stats = dm.stats
+                else:
+                    dm.grads.zero_()
+                    ev.record()
+                    stats = torch.zeros_like(dm.stats)
+                dp.sync_grads(dm.grads, dm.grad_split, ev, state=state, state_weight=weight)
         else:
             dm.train_fwd_bwd(self._features_of(xb, is_audio), yb, cw, dropout_seed=seed, ignore_index=ignore_index)
             stats = dm.stats

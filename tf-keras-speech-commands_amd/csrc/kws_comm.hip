@@ -2,17 +2,22 @@
 //
 // The reference trains in one process (train.py:81-92, model.fit(workers=1)); this component is new (SURVEY section 5,
 // "Distributed communication backend").  The exchange of a train step is ONE sum-all-reduce of the flat fp32 gradient
-// buffer (134 932 floats = 540 KB for simple_cnn), issued as two buckets on the communicator's own stream:
-//   early bucket  grads[split, n)   conv4 + BN4 + dense + head, 82 % of the bytes, final first -> starts behind the
-//                                   library's bucket_event while conv3 .. conv1 backward still run on the caller's stream
-//   late bucket   grads[0, split)   + the BatchNormalization moving statistics (weighted mean over ranks), one RCCL group
-// and the caller's stream waits for the communicator's stream before the optimizer step.
+// buffer (134 932 floats = 540 KB for simple_cnn), issued as two buckets:
+//   early bucket  grads[split, n)   conv4 + BN4 + dense + head, 82 % of the bytes, final first -> inside the train step
+//                                   (kws_train_args.comm) it is enqueued on the MODEL's side stream right behind conv4's weight
+//                                   gradient, i.e. while conv3 .. conv1 backward still run on the caller's stream
+//   late bucket   grads[0, split)   + the BatchNormalization moving statistics (weighted mean over ranks), one RCCL group on
+//                                   the caller's stream behind the backward pass.
+// The communicator owns NO stream: a collective on a stream of its own stalled the device by ~1.1 ms per step (0.65 -> 1.79 ms
+// with a one-rank communicator; the same call on a stream that already carries the step's kernels costs nothing: tools/commbench.py),
+// so every collective is enqueued on a stream the step already uses.
 //
 // RCCL is bound at run time (dlopen): a process that already holds a librccl.so.1 (PyTorch ships one) shares that
 // instance, a torch-free host loads the system one from the ROCm library path.  libkws_hip.so itself has no link-time
 // dependency on RCCL, so single-GPU users never load it.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -95,8 +100,6 @@ __global__ void scale_kernel(float *__restrict__ x, long n, float a)
 struct kws_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
-    hipStream_t stream = nullptr;        // every collective of this communicator is issued here, in call order
-    hipEvent_t ev_main = nullptr, ev_done = nullptr;
     bool timing = false;
     hipEvent_t t[4] = {nullptr, nullptr, nullptr, nullptr};   // early bucket begin / end, late bucket begin / end
     bool timed_early = false, timed_late = false;
@@ -130,17 +133,12 @@ int kws_comm_init(int rank, int world, const void *unique_id, kws_comm **out)
     std::memcpy(u.internal, unique_id, KWS_COMM_ID_BYTES);
     int rc = r->CommInitRank(&c->comm, world, u, rank);
     if (rc != ncclSuccessV) { delete c; return rccl_fail("ncclCommInitRank", rc); }
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); greatest = 0; }
-    // highest priority: the collective is latency-bound (540 KB) and must not queue behind the weight-gradient kernels
-    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+    hipError_t e = hipSuccess;
     for (auto &t : c->t)
         if (e == hipSuccess) e = hipEventCreate(&t);
     if (e != hipSuccess) {
         kws_comm_destroy(c);
-        return fail(KWS_ERR_HIP, "communicator stream / events: %s", hipGetErrorString(e));
+        return fail(KWS_ERR_HIP, "communicator timing events: %s", hipGetErrorString(e));
     }
     *out = c;
     return KWS_OK;
@@ -150,13 +148,10 @@ void kws_comm_destroy(kws_comm *c)
 {
     if (!c) return;
     Rccl *r = rccl();
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize();
     if (c->comm && r) (void)r->CommDestroy(c->comm);
-    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
-    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     for (auto &t : c->t)
         if (t) (void)hipEventDestroy(t);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     (void)hipGetLastError();
     delete c;
 }
@@ -174,43 +169,61 @@ int kws_comm_info(const kws_comm *c, int *rank, int *world, int *rccl_version)
     return KWS_OK;
 }
 
-int kws_allreduce_grads(kws_comm *c, float *grads, int64_t n, int64_t split, void *bucket_event, float *state, int64_t n_state,
-                        float state_weight, void *stream)
+}  // extern "C"
+
+namespace kws {
+
+// early bucket: one all-reduce on `s` (the train step passes its side stream)
+int comm_allreduce_early(kws_comm *c, float *buf, int64_t n, hipStream_t s)
 {
-    if (!c || !grads) return fail(KWS_ERR_INVALID, "null argument");
-    if (n < 0 || split < 0 || split > n || n_state < 0 || (n_state > 0 && !state)) return fail(KWS_ERR_INVALID, "bad bucket sizes");
+    if (!c || !buf || n <= 0) return KWS_OK;
     Rccl *r = rccl();
     if (!r) return fail(KWS_ERR_COMM, "RCCL is not available");
-    hipStream_t s = static_cast<hipStream_t>(stream), cs = c->stream;
-    c->timed_early = c->timed_late = false;
-    const bool early = bucket_event && split > 0 && split < n;
-    if (early) {
-        // the early bucket is final when bucket_event fires (kws_train_args.bucket_event): reduce it while the rest of the
-        // backward pass runs on the caller's stream
-        KWS_HIP_CHECK(hipStreamWaitEvent(cs, static_cast<hipEvent_t>(bucket_event), 0));
-        if (c->timing) KWS_HIP_CHECK(hipEventRecord(c->t[0], cs));
-        KWS_RCCL_CHECK("ncclAllReduce (early bucket)", r->AllReduce(grads + split, grads + split, (size_t)(n - split), ncclFloat32, ncclSum, c->comm, cs));
-        if (c->timing) { KWS_HIP_CHECK(hipEventRecord(c->t[1], cs)); c->timed_early = true; }
-    }
-    // everything the caller has enqueued so far (the whole backward pass) precedes the late bucket
-    KWS_HIP_CHECK(hipEventRecord(c->ev_main, s));
-    KWS_HIP_CHECK(hipStreamWaitEvent(cs, c->ev_main, 0));
-    if (c->timing) KWS_HIP_CHECK(hipEventRecord(c->t[2], cs));
-    const int64_t late_n = early ? split : n;
+    c->timed_early = false;
+    if (c->timing) KWS_HIP_CHECK(hipEventRecord(c->t[0], s));
+    KWS_RCCL_CHECK("ncclAllReduce (early bucket)", r->AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, c->comm, s));
+    if (c->timing) { KWS_HIP_CHECK(hipEventRecord(c->t[1], s)); c->timed_early = true; }
+    return KWS_OK;
+}
+
+// late bucket + state * weight, one RCCL group on `s`
+int comm_allreduce_late(kws_comm *c, float *grads, int64_t n, float *state, int64_t n_state, float state_weight, hipStream_t s)
+{
+    if (!c) return fail(KWS_ERR_INVALID, "null communicator");
+    Rccl *r = rccl();
+    if (!r) return fail(KWS_ERR_COMM, "RCCL is not available");
+    c->timed_late = false;
+    if (n <= 0 && n_state <= 0) return KWS_OK;
+    if (c->timing) KWS_HIP_CHECK(hipEventRecord(c->t[2], s));
     if (n_state > 0 && state_weight != 1.0f)
-        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n_state + 255) / 256)), dim3(256), 0, cs, state, (long)n_state, state_weight);
+        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n_state + 255) / 256)), dim3(256), 0, s, state, (long)n_state, state_weight);
     KWS_RCCL_CHECK("ncclGroupStart", r->GroupStart());
-    int rc1 = late_n > 0 ? r->AllReduce(grads, grads, (size_t)late_n, ncclFloat32, ncclSum, c->comm, cs) : ncclSuccessV;
-    int rc2 = n_state > 0 ? r->AllReduce(state, state, (size_t)n_state, ncclFloat32, ncclSum, c->comm, cs) : ncclSuccessV;
+    const int rc1 = n > 0 ? r->AllReduce(grads, grads, (size_t)n, ncclFloat32, ncclSum, c->comm, s) : ncclSuccessV;
+    const int rc2 = n_state > 0 ? r->AllReduce(state, state, (size_t)n_state, ncclFloat32, ncclSum, c->comm, s) : ncclSuccessV;
     const int rc3 = r->GroupEnd();
     if (rc1 != ncclSuccessV) return rccl_fail("ncclAllReduce (late bucket)", rc1);
     if (rc2 != ncclSuccessV) return rccl_fail("ncclAllReduce (BatchNormalization statistics)", rc2);
     if (rc3 != ncclSuccessV) return rccl_fail("ncclGroupEnd", rc3);
-    if (c->timing) { KWS_HIP_CHECK(hipEventRecord(c->t[3], cs)); c->timed_late = true; }
-    KWS_HIP_CHECK(hipEventRecord(c->ev_done, cs));
-    KWS_HIP_CHECK(hipStreamWaitEvent(s, c->ev_done, 0));
+    if (c->timing) { KWS_HIP_CHECK(hipEventRecord(c->t[3], s)); c->timed_late = true; }
     KWS_LAUNCH_CHECK("gradient exchange");
     return KWS_OK;
+}
+
+}  // namespace kws
+
+extern "C" {
+
+int kws_allreduce_grads(kws_comm *c, float *grads, int64_t n, int64_t split, float *state, int64_t n_state, float state_weight, void *stream)
+{
+    if (!c || !grads) return fail(KWS_ERR_INVALID, "null argument");
+    if (n < 0 || split < 0 || split > n || n_state < 0 || (n_state > 0 && !state)) return fail(KWS_ERR_INVALID, "bad bucket sizes");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the same two collectives, in the same order, as a train step with kws_train_args.comm issues: ranks may mix the two forms
+    // (a rank whose shard of a partial batch is empty calls this on a cleared gradient buffer)
+    const bool two = split > 0 && split < n;
+    if (two)
+        if (int rc = comm_allreduce_early(c, grads + split, n - split, s)) return rc;
+    return comm_allreduce_late(c, grads, two ? split : n, state, n_state, state_weight, s);
 }
 
 int kws_comm_allreduce(kws_comm *c, void *buf, int64_t n, int dtype, int op, void *stream)
@@ -234,13 +247,7 @@ int kws_comm_allreduce(kws_comm *c, void *buf, int64_t n, int dtype, int op, voi
     case KWS_OP_AVG: ro = ncclAvg; break;
     default: return fail(KWS_ERR_INVALID, "unknown reduction %d", op);
     }
-    // ordered with the caller's stream on both sides, executed on the communicator's stream like every other collective
-    hipStream_t s = static_cast<hipStream_t>(stream), cs = c->stream;
-    KWS_HIP_CHECK(hipEventRecord(c->ev_main, s));
-    KWS_HIP_CHECK(hipStreamWaitEvent(cs, c->ev_main, 0));
-    KWS_RCCL_CHECK("ncclAllReduce", r->AllReduce(buf, buf, (size_t)n, dt, ro, c->comm, cs));
-    KWS_HIP_CHECK(hipEventRecord(c->ev_done, cs));
-    KWS_HIP_CHECK(hipStreamWaitEvent(s, c->ev_done, 0));
+    KWS_RCCL_CHECK("ncclAllReduce", r->AllReduce(buf, buf, (size_t)n, dt, ro, c->comm, static_cast<hipStream_t>(stream)));
     return KWS_OK;
 }
 

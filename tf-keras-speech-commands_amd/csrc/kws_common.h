@@ -43,6 +43,10 @@ inline int fail(int code, const char *fmt, ...)
 // instead of being masked after the load, so a fragment load has no consumer until its MFMA (the prefetch can overlap).
 const float *zero_page();
 
+// gradient exchange on streams the train step already uses (kws_comm.hip)
+int comm_allreduce_early(kws_comm *c, float *buf, int64_t n, hipStream_t s);
+int comm_allreduce_late(kws_comm *c, float *grads, int64_t n, float *state, int64_t n_state, float state_weight, hipStream_t s);
+
 // library-wide defaults of the per-model precision attributes (kws_model_set_precision)
 int default_matrix_precision();
 int default_infer_precision();

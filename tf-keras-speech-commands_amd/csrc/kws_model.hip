@@ -531,7 +531,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
 // ---- backward -----------------------------------------------------------------------------------------------
 int cnn_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
                  hipEvent_t bucket_event, hipStream_t s, float *stats, bool grads_zeroed = false, const double *moments = nullptr,
-                 OverlapHook *hook = nullptr)
+                 OverlapHook *hook = nullptr, kws_comm *comm = nullptr)
 {
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
@@ -633,13 +633,12 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
             if (mprec == 1) KWS_TRY(launch_wgrad_bf16<64, 128, 1, true>(in, nullptr, dk, g, s2, w.dzp, det));
             else KWS_TRY(launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2, det));
-            if (bucket_event) {
-                // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here: it
-                // runs the dense and conv4 weight gradients in order and joined the caller's stream at fork(3), i.e. after
-                // head_bwd, the dense bias sums and BN4's backward.  Recorded on the side stream, so the caller's stream does
-                // not wait for the conv4 wgrad.
-                KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
-            }
+            // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here: it
+            // runs the dense and conv4 weight gradients in order and joined the caller's stream at fork(3), i.e. after
+            // head_bwd, the dense bias sums and BN4's backward.  The early bucket's all-reduce goes right here, on the side stream
+            // (the caller's stream does not wait for the conv4 wgrad, and the collective runs under the rest of the backward pass).
+            if (comm) KWS_TRY(comm_allreduce_early(comm, grads + m->o_k[3], m->P - m->o_k[3], s2));
+            if (bucket_event) KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
             if (mprec == 1 && blocks_for((long)B * Hs[3] * Ws[3], 64) <= (unsigned)kStatStride) {
                 // the data gradient's epilogue is BatchNorm 3's backward reduction (conv3 has no pooling): it gates by ReLU6(y3), stores
                 // g in gz[2] and leaves the partial sums of g and g xhat -- no bn_bwd_reduce pass over (z3, da3)
@@ -1069,6 +1068,13 @@ int kws_feature_moments(const float *feat, int B, int n_features, int feature_si
     return KWS_OK;
 }
 
+int kws_model_bind_device(kws_model *m)
+{
+    if (!m) return fail(KWS_ERR_INVALID, "null argument");
+    if (!m->dev_res()) return fail(KWS_ERR_HIP, "cannot create the model's side stream / events on this device");
+    return KWS_OK;
+}
+
 int kws_model_prepare_inference(kws_model *m, int B, const float *params, const float *state, void *ws, size_t ws_bytes, void *stream)
 {
     if (!m || !params || !state) return fail(KWS_ERR_INVALID, "null argument");
@@ -1243,7 +1249,12 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
 {
     if (!m || !a || !a->feat || !a->labels || !a->params || !a->state || !a->grads) return fail(KWS_ERR_INVALID, "null argument");
     if (a->B < 1) return fail(KWS_ERR_INVALID, "batch must be >= 1");
-    if (m->kind == KWS_SIMPLE_GRU || m->kind == KWS_SIMPLE_LSTM) return gru_train_fwd_bwd(m, a, static_cast<hipStream_t>(stream));
+    if (m->kind == KWS_SIMPLE_GRU || m->kind == KWS_SIMPLE_LSTM) {
+        if (int rc = gru_train_fwd_bwd(m, a, static_cast<hipStream_t>(stream))) return rc;
+        // recurrent models have no BatchNormalization and one bucket: the whole exchange behind the backward pass
+        if (a->comm) return comm_allreduce_late(a->comm, a->grads, m->P, nullptr, 0, 1.f, static_cast<hipStream_t>(stream));
+        return KWS_OK;
+    }
     CnnWs w;
     int rc = check_ws(m, a->B, true, a->ws, a->ws_bytes, w);
     if (rc) return rc;
@@ -1269,9 +1280,14 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     if (rc) return rc;
     if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
     if (!lite) KWS_TRY(hook.fire(1, s));
-    return lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
-                : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s,
-                               fuse_stats ? a->stats : nullptr, grads_zeroed, a->feat_moments, &hook);
+    rc = lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
+              : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s,
+                             fuse_stats ? a->stats : nullptr, grads_zeroed, a->feat_moments, &hook, a->comm);
+    if (rc || !a->comm) return rc;
+    // simple_cnn reduced its early bucket on the side stream (joined again by now); the rest, and the BatchNormalization moving
+    // statistics, go behind the backward pass on the caller's stream.  simple_cnn_lite has no side stream: both buckets here.
+    if (lite) KWS_TRY(comm_allreduce_early(a->comm, a->grads + m->o_k[3], m->P - m->o_k[3], s));
+    return comm_allreduce_late(a->comm, a->grads, m->o_k[3], a->state, m->S, a->comm_state_weight, s);
 }
 
 int kws_set_matrix_precision(int mode)

@@ -40,7 +40,8 @@ class KwsTrainArgs(ctypes.Structure):
                 ("ws_bytes", ctypes.c_size_t), ("dropout_seed", ctypes.c_uint64), ("grad_scale", ctypes.c_float),
                 ("probs", ctypes.c_void_p), ("stats", ctypes.c_void_p), ("bucket_event", ctypes.c_void_p),
                 ("forward_event", ctypes.c_void_p), ("overlap_event", ctypes.c_void_p),
-                ("overlap_callback", OVERLAP_CB), ("overlap_user", ctypes.c_void_p), ("feat_moments", ctypes.c_void_p)]
+                ("overlap_callback", OVERLAP_CB), ("overlap_user", ctypes.c_void_p), ("comm", ctypes.c_void_p),
+                ("comm_state_weight", ctypes.c_float), ("feat_moments", ctypes.c_void_p)]
 
 
 MODEL_KINDS = {"simple_cnn": 0, "simple_cnn_lite": 1, "simple_gru": 2, "simple_lstm": 3}
@@ -89,6 +90,7 @@ def get_lib():
     L.kws_model_workspace_bytes.restype = i64
     L.kws_model_forward.argtypes = [vp, vp, i32, vp, vp, vp, ctypes.c_size_t, vp, vp, vp]
     L.kws_model_train_fwd_bwd.argtypes = [vp, ctypes.POINTER(KwsTrainArgs), vp]
+    L.kws_model_bind_device.argtypes = [vp]
     L.kws_model_prepare_inference.argtypes = [vp, i32, vp, vp, vp, ctypes.c_size_t, vp]
     L.kws_model_invalidate_prepared.argtypes = [vp]
     L.kws_feature_moments_workspace_bytes.argtypes = [i32]
@@ -125,7 +127,7 @@ def get_lib():
     L.kws_comm_destroy.argtypes = [vp]
     L.kws_comm_destroy.restype = None
     L.kws_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
-    L.kws_allreduce_grads.argtypes = [vp, vp, i64, i64, vp, vp, i64, f32, vp]
+    L.kws_allreduce_grads.argtypes = [vp, vp, i64, i64, vp, i64, f32, vp]
     L.kws_comm_allreduce.argtypes = [vp, vp, i64, i32, i32, vp]
     L.kws_comm_timing.argtypes = [vp, i32]
     L.kws_comm_last_us.argtypes = [vp, ctypes.POINTER(f32), ctypes.POINTER(f32)]

@@ -99,6 +99,8 @@ class DeviceModel(object):
         self.grads, self.adam_m, self.adam_v = z(spec.param_count), z(spec.param_count), z(spec.param_count)
         self.stats = torch.zeros((2,), dtype=torch.float32, device=self.device)
         self.step_count = 0
+        # the model's side stream exists from here on: before any communicator / pipeline creates streams of its own (kws_model_bind_device)
+        _l.check(self._L.kws_model_bind_device(spec.handle))
         self._matrix = self._infer = None      # per-model precision attributes (None: library default)
         self._ws = None
         self._ws_key = None
@@ -213,11 +215,13 @@ class DeviceModel(object):
 
     def train_fwd_bwd(self, feat, labels, class_weights=None, dropout_seed=0, grad_scale=1.0, want_probs=False,
                       ignore_index=0, bucket_event=None, forward_event=None, overlap_event=None, overlap_callback=None,
-                      feat_moments=None):
+                      feat_moments=None, comm=None, comm_state_weight=1.0):
         """labels: CUDA int32 (B,); class_weights: CUDA float32 (C,) or None.  Leaves grads in self.grads and
         {sum of losses, top-1 hits} in self.stats (device).  bucket_event: torch.cuda.Event recorded when the early
         gradient bucket [grad_split, P) is final.  feat_moments: the float64 CUDA tensor feature_moments(feat) returned (optional;
-        simple_cnn then skips its own moment pass at the head of the step)."""
+        simple_cnn then skips its own moment pass at the head of the step).  comm: a kws_amd.parallel.KwsComm -- the step then sums its
+        gradients (and the BatchNormalization statistics times comm_state_weight) over the ranks itself, the early bucket under
+        the rest of the backward pass; pass grad_scale = comm_state_weight = local clips / global clips."""
         torch = _torch()
         B = self._check_feat(feat)
         if labels.dtype != torch.int32 or not labels.is_cuda or labels.numel() != B:
@@ -233,6 +237,9 @@ class DeviceModel(object):
         a.dropout_seed, a.grad_scale = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, float(grad_scale)
         a.probs = probs.data_ptr() if want_probs else None
         a.stats = self.stats.data_ptr()
+        if comm is not None:
+            a.comm = comm.handle
+            a.comm_state_weight = float(comm_state_weight)
         if feat_moments is not None:
             if feat_moments.dtype != torch.float64 or not feat_moments.is_cuda or feat_moments.numel() != _l.FEATURE_MOMENTS:
                 raise ValueError("feat_moments must be the %d float64 values of feature_moments()" % _l.FEATURE_MOMENTS)

@@ -4,8 +4,8 @@ The train step shards the global batch across ranks; the only collective on the 
 flat gradient buffer (134 932 floats for simple_cnn), issued as two buckets so that the first (conv4 + dense + head, 82 %
 of the bytes, produced first by the backward pass) overlaps the rest of the backward.
 
-On GPUs the exchange goes through the C ABI (`kws_comm_*`, `kws_allreduce_grads`: RCCL over xGMI on the communicator's
-own stream, csrc/kws_comm.hip); torch.distributed is only the bootstrap (it ships the 128-byte RCCL id) and the control
+On GPUs the exchange goes through the C ABI (`kws_comm_*`: RCCL over xGMI, enqueued by the train step itself on streams it
+already uses -- `kws_train_args.comm` -- or by `kws_allreduce_grads`, csrc/kws_comm.hip); torch.distributed is only the bootstrap (it ships the 128-byte RCCL id) and the control
 plane (barriers, logging sums).  CPU tensors (the gloo tests) take the torch.distributed path with the same bucket /
 weight arithmetic."""
 import ctypes
@@ -29,6 +29,10 @@ def is_distributed():
 
 def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them)."""
+    # two HIP hardware queues: with an RCCL communicator in the process the default of four dealt the step's three streams so that
+    # its fork/join branches serialised (0.72 -> 1.2 ms/step at B = 4096, DESIGN.md section 6).  Only read by the HIP runtime at its
+    # first call, so this must run before anything touches the GPU; a value already in the environment wins.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     import torch
     d = _dist()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -44,7 +48,8 @@ def init_from_env(backend=None):
 
 
 class KwsComm(object):
-    """Owner of a `kws_comm` handle (include/kws.h): an RCCL communicator on the current device plus its stream."""
+    """Owner of a `kws_comm` handle (include/kws.h): an RCCL communicator on the current device (it owns no stream: every
+    collective is enqueued on a stream the caller names)."""
 
     def __init__(self, rank, world, unique_id):
         self._L = _l.get_lib()
@@ -62,11 +67,28 @@ class KwsComm(object):
         _l.check(_l.get_lib().kws_comm_unique_id(buf))
         return buf.raw
 
+    _store_seq = 0
+
     @classmethod
     def from_torch_group(cls, group=None):
-        """Bootstrap over an initialised torch.distributed group (any backend): rank 0's id is broadcast as an object."""
+        """Bootstrap over an initialised torch.distributed group (any backend).  Rank 0's 128-byte id travels through the group's
+        key-value store when it is reachable (no collective, so torch does not build its own NCCL communicator -- and that one's
+        streams -- in front of ours: the order in which streams are created decides which hardware queues they share), else as a
+        broadcast object."""
         d = _dist()
         rank, world = d.get_rank(group), d.get_world_size(group)
+        store = None
+        if group is None:
+            try:
+                store = d.distributed_c10d._get_default_store()
+            except Exception:
+                store = None
+        if store is not None:
+            key = "kws_comm_id_%d" % cls._store_seq
+            cls._store_seq += 1
+            if rank == 0:
+                store.set(key, cls.unique_id())
+            return cls(rank, world, bytes(store.get(key)))
         box = [cls.unique_id() if rank == 0 else None]
         d.broadcast_object_list(box, src=d.get_global_rank(group, 0) if group is not None else 0, group=group)
         return cls(rank, world, box[0])
@@ -82,12 +104,15 @@ class KwsComm(object):
         _l.check(self._L.kws_comm_info(self._h, None, None, ctypes.byref(v)))
         return v.value
 
-    def allreduce_grads(self, grads, split=0, bucket_event=None, state=None, state_weight=1.0):
+    @property
+    def handle(self):
+        return self._h
+
+    def allreduce_grads(self, grads, split=0, state=None, state_weight=1.0):
+        """kws_allreduce_grads: the exchange as a call of its own, on the current stream (a train step given `comm=` does it
+        itself, with the early bucket overlapped; ranks may mix the two forms: same collectives, same order)."""
         import torch
-        if bucket_event is not None and not bucket_event.cuda_event:
-            raise ValueError("bucket_event has not been recorded (pass the event given to train_fwd_bwd)")
         _l.check(self._L.kws_allreduce_grads(self._h, grads.data_ptr(), grads.numel(), int(split or 0),
-                                             bucket_event.cuda_event if bucket_event is not None else None,
                                              state.data_ptr() if state is not None else None,
                                              state.numel() if state is not None else 0, float(state_weight),
                                              torch.cuda.current_stream().cuda_stream))
@@ -179,7 +204,7 @@ class DataParallel(object):
             return
         w = (1.0 / self.world) if state_weight is None else float(state_weight)
         if self.comm is not None and grads.is_cuda:
-            self.comm.allreduce_grads(grads, split or 0, bucket_event, state, w)
+            self.comm.allreduce_grads(grads, split or 0, state, w)
             return
         d = _dist()
         if grads.is_cuda and split and bucket_event is not None:

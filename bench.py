@@ -499,11 +499,13 @@ def main():
                 trec = json.load(f)
             rec = trec.get(name)
             if rec and rec.get("batch") == B:
-                if rec.get("source_sha1") == L.build_id().get(rec.get("source_file")):
+                bid = L.build_id()
+                srcs = rec.get("sources") or {rec.get("source_file"): rec.get("source_sha1")}
+                if srcs and all(bid.get(fn) == sha for fn, sha in srcs.items()):
                     traffic, traffic_note = rec["traffic_bytes_per_launch"], "profiles/%s" % os.path.basename(TRAFFIC_RECORD)
                 else:
-                    traffic_note = "PMC record is stale (measured on %s %s, library built from %s)" % (
-                        rec.get("source_file"), rec.get("source_sha1"), L.build_id().get(rec.get("source_file")))
+                    traffic_note = "PMC record is stale (measured on %s, library built from %s)" % (
+                        srcs, {fn: bid.get(fn) for fn in srcs})
         except (OSError, ValueError):
             pass
         alone_ms = rep_serial[name]["total_ms"] / rep_serial[name]["count"]

@@ -1,10 +1,13 @@
 // csrc/kws_common.h -- shared host-side helpers for the C-ABI implementation (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <string>
+#include <tuple>
+#include <utility>
 
 #include "kws.h"
 
@@ -51,23 +54,45 @@ int comm_allreduce_late(kws_comm *c, float *grads, int64_t n, float *state, int6
 int default_matrix_precision();
 int default_infer_precision();
 
-// Opt-in per-launch timing (kws_prof_enable / kws_prof_report): HIP events recorded on the launch stream around each
-// kernel.  Disabled (the default) it costs one relaxed load per launch site.
+// Opt-in per-launch timing (kws_prof_enable / kws_prof_report).  A profiled launch goes through hipExtLaunchKernel with a start and a stop
+// event bound to the dispatch itself, so the reported time is the kernel's own begin -> end (what rocprofv3 --kernel-trace reports), without
+// the barrier packets event records around a launch would add between concurrent streams.  Disabled (the default) it costs one relaxed load
+// per launch site.
 bool prof_on();
 const char *prof_name(const char *base, int layer);   // interned "<base>.L<layer>" while profiling, else base
-void prof_mark(const char *name, hipStream_t s, bool begin);
-struct ProfScope {
-    const char *name;
-    hipStream_t s;
-    bool on;
-    ProfScope(const char *n, hipStream_t st) : name(n), s(st), on(prof_on()) { if (on) prof_mark(name, s, true); }
-    ~ProfScope() { if (on) prof_mark(name, s, false); }
-};
+void prof_events(const char *name, hipEvent_t *e0, hipEvent_t *e1);   // a fresh pair, remembered under `name`
+
+template <size_t I, typename Tuple>
+inline void set_launch_args(Tuple &) {}
+template <size_t I, typename Tuple, typename A, typename... Rest>
+inline void set_launch_args(Tuple &t, A &&a, Rest &&...rest)
+{
+    std::get<I>(t) = static_cast<std::tuple_element_t<I, Tuple>>(std::forward<A>(a));    // the conversion a <<<>>> call would apply
+    set_launch_args<I + 1>(t, std::forward<Rest>(rest)...);
+}
+template <typename... KArgs, typename... Args, size_t... I>
+inline void launch_timed_impl(const char *name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t s,
+                              std::index_sequence<I...>, Args &&...args)
+{
+    // trailing parameters the call leaves out take a zero value: every default argument of this library's kernels is nullptr / 0 / empty planes
+    std::tuple<std::remove_cv_t<KArgs>...> vals{};
+    set_launch_args<0>(vals, std::forward<Args>(args)...);
+    void *ptrs[sizeof...(KArgs) + 1] = {static_cast<void *>(&std::get<I>(vals))..., nullptr};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    prof_events(name, &e0, &e1);
+    (void)hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, smem, s, e0, e1, 0);
+}
+template <typename... KArgs, typename... Args>
+inline void launch_timed(const char *name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t s, Args &&...args)
+{
+    static_assert(sizeof...(Args) <= sizeof...(KArgs), "argument count of a kernel launch");
+    launch_timed_impl(name, kernel, grid, block, smem, s, std::index_sequence_for<KArgs...>{}, std::forward<Args>(args)...);
+}
 
 }  // namespace kws
 
-#define KWS_LAUNCH(name, kernel, grid, block, smem, stream, ...)          \
-    do {                                                                 \
-        ::kws::ProfScope prof__(name, stream);                           \
-        hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__); \
+#define KWS_LAUNCH(name, kernel, grid, block, smem, stream, ...)                                              \
+    do {                                                                                                     \
+        if (::kws::prof_on()) ::kws::launch_timed(name, kernel, dim3(grid), dim3(block), smem, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                             \
     } while (0)

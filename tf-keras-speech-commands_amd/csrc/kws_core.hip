@@ -56,17 +56,13 @@ const char *prof_name(const char *base, int layer)
     return interned.emplace(key, key).first->second.c_str();
 }
 
-void prof_mark(const char *name, hipStream_t s, bool begin)
+void prof_events(const char *name, hipEvent_t *e0, hipEvent_t *e1)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (begin) {
-        ProfRec r{name, take_event(), take_event()};
-        (void)hipEventRecord(r.e0, s);
-        g_prof.push_back(r);
-    } else {
-        for (size_t i = g_prof.size(); i-- > 0;)
-            if (g_prof[i].name == name) { (void)hipEventRecord(g_prof[i].e1, s); break; }
-    }
+    ProfRec r{name, take_event(), take_event()};
+    g_prof.push_back(r);
+    *e0 = r.e0;
+    *e1 = r.e1;
 }
 }  // namespace kws
 

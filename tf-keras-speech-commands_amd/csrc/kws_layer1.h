@@ -362,12 +362,95 @@ __device__ __forceinline__ void l1m_reduce_store(double s0, double s1, double *_
     }
 }
 
+// Forward body (conv1 -> BN -> ReLU6 -> 2x2 max) for a compile-time map size, shared by the training and the inference kernel.  The
+// generic loop below visits the windows four at a time in index order and pays a coordinate walk with wrap loops per tile; a1 does
+// not care in which order it is written, so quadrant q of every tile walks its own contiguous run of windows (window = q * NT + t):
+// a lane's window advances by one per tile -- +2 floats or the row jump, one compare and two selects -- and the z product of tile
+// t+1 is issued before tile t is finished (kws_layer1_fast.h has the backward pass in the same form).
+template <int H, int W>
+__device__ __forceinline__ void l1f_forward_clips(const float *__restrict__ feat, const float *__restrict__ wk, float sc, float sh,
+                                                  float *__restrict__ a1, int B, int clips_per_wave, float *smem)
+{
+    constexpr int WP = W + 2, Wp = W / 2, Hp = H / 2, NWIN = Hp * Wp, NT = (NWIN + 3) / 4, NXS = (H + 2) * WP, HW = H * W;
+    constexpr int NST = (NXS + 63) / 64, LAST = NWIN - 3 * NT, kWrap = 2 * WP - 2 * (Wp - 1), UN = 6;
+    static_assert(H % 2 == 0 && W % 2 == 0 && LAST > 0 && LAST <= NT && NST <= kL1Stage, "map size");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
+    float *xs = smem + wave * ((NXS + 3) & ~3);
+    float wb[3];
+    int aoff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int tap = 4 * j + lq, tc = tap < 9 ? tap : 8;
+        wb[j] = tap < 9 ? wk[tap * 16 + li] : 0.f;
+        aoff[j] = (tc / 3) * WP + tc % 3;
+    }
+    int soff[NST];
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+        const int i = lane + 64 * j, r = i / WP - 1, c = i % WP - 1;
+        soff[j] = (i < NXS && r >= 0 && r < H && c >= 0 && c < W) ? r * W + c : -1;
+    }
+    long first;
+    int count;
+    l1m_clips(B, clips_per_wave, first, count);
+    const int qa = li >> 2, e = li & 3, eoff = (e >> 1) * WP + (e & 1);
+    const int wa0 = qa * NT, a_ph0 = wa0 / Wp, a_pw0 = wa0 - a_ph0 * Wp;
+    const int cnt = lq < 3 ? NT : LAST;                  // windows of the quadrant this lane stores
+    float pre[NST];
+    auto fetch = [&](long b) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) pre[j] = soff[j] >= 0 ? feat[b * HW + soff[j]] : 0.f;
+    };
+    if (count > 0) fetch(first);
+    for (int i = 0; i < count; ++i) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+            const int q = lane + 64 * j;
+            if (q < NXS) xs[q] = pre[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (i + 1 < count) fetch(first + i + 1);
+        float *out = a1 + ((first + i) * NWIN + lq * NT) * 16 + li;
+        int a_pw = a_pw0, a_off = 2 * a_ph0 * WP + 2 * a_pw0 + eoff;
+        auto zprod = [&](int t) {
+            const int ao = (t < LAST || qa < 3) ? a_off : eoff;      // past the clip: window 0, never stored
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc = mfma16(xs[ao + aoff[j]], wb[j], acc);
+            const bool wrap = ++a_pw == Wp;
+            a_pw = wrap ? 0 : a_pw;
+            a_off += wrap ? kWrap : 2;
+            return acc;
+        };
+        f32x4 z = zprod(0);
+#pragma nounroll
+        for (int t0 = 0; t0 < NT; t0 += UN) {
+#pragma unroll
+            for (int jt = 0; jt < UN; ++jt) {
+                const int t = t0 + jt;
+                if (NT % UN != 0 && t >= NT) continue;
+                const f32x4 zn = zprod(t + 1);          // one product past the last tile: a valid address, the result is dropped
+                const float y0 = fmaf(z[0], sc, sh), y1 = fmaf(z[1], sc, sh), y2 = fmaf(z[2], sc, sh), y3 = fmaf(z[3], sc, sh);
+                if (t < cnt) out[t * 16] = relu6f(fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
+                z = zn;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void l1m_act_pool_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
                                                             const float *__restrict__ scale, const float *__restrict__ shift,
                                                             float *__restrict__ a1, int B, int H, int W, int clips_per_wave)
 {
     extern __shared__ float l1smem[];
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    if (H == 30 && W == 20) {                     // the default map: compile-time form
+        l1f_forward_clips<30, 20>(feat, wk, scale[li], shift[li], a1, B, clips_per_wave, l1smem);
+        return;
+    }
     L1Mma t;
     t.init(wk, H, W, l1smem);
     long first;

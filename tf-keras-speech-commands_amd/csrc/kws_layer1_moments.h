@@ -165,6 +165,11 @@ __global__ __launch_bounds__(256) void l1m_act_pool_moments_kernel(const float *
         }
     }
     const int lane = threadIdx.x & 63, li = lane & 15, lq = lane >> 4;
+    if (H == 30 && W == 20) {                     // the default map: compile-time form (kws_layer1.h: l1f_forward_clips)
+        __syncthreads();
+        l1f_forward_clips<30, 20>(feat, wk, s_sc[li], s_sh[li], a1, B, clips_per_wave, l1smem);
+        return;
+    }
     L1Mma t;
     t.init(wk, H, W, l1smem);
     long first;

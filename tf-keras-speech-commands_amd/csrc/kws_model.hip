@@ -14,6 +14,7 @@
 #include "kws_layers.h"
 #include "kws_layer1.h"
 #include "kws_layer1_moments.h"
+#include "kws_layer1_fast.h"
 #include "kws_lite.h"
 #include "kws_lite_f16.h"
 
@@ -721,8 +722,12 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         if (l1m) {
             // one pass collects G, sum g, sum g z per block (double partials, fixed order); the closed forms of dW1, dgamma, dbeta use Q
             const double *q = moments ? moments : w.moments;
-            KWS_LAUNCH("l1m_bwd_onepass_kernel", l1m_bwd_onepass_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0, cpw,
-                       w.partial);
+            // the default map (30 frames x 20 coefficients) has a fully unrolled form with its own window walk (kws_layer1_fast.h)
+            if (d.H0 == 30 && d.W0 == 20)
+                KWS_LAUNCH("l1m_bwd_onepass_kernel", (l1f_bwd_onepass_kernel<30, 20>), dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, cpw, w.partial);
+            else
+                KWS_LAUNCH("l1m_bwd_onepass_kernel", l1m_bwd_onepass_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0, cpw,
+                           w.partial);
             KWS_LAUNCH("l1_bwd_finalize_moments_kernel", l1_bwd_finalize_moments_kernel, dim3(144 + 16), dim3(64), 0, s, w.partial, nbm, q, kern1,
                        params + m->o_g[0], k1, grads + m->o_k[0], grads + m->o_g[0], grads + m->o_b[0]);
         } else {

@@ -23,6 +23,8 @@ struct ConvGeom {
     int B, H, W, Ho, Wo;   // input and output spatial sizes (NHWC)
     int stride, pt, pl;    // TF 'SAME': pad_top / pad_left (the extra pad, if any, is bottom/right)
     int KH, KW;
+    // conv_bf16_kernel only: rows in pixel-major order (row q = pixel q / B of clip q % B instead of clip-major), see there
+    int pmajor = 0;
 };
 
 enum { EPI_NONE = 0, EPI_RELU = 1, EPI_BIAS_RELU6 = 2, EPI_BIAS = 3, EPI_BIAS_RELU = 4,
@@ -248,7 +250,37 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
     const int SH = MODE == MODE_FWD ? g.H : g.Ho, SW = MODE == MODE_FWD ? g.W : g.Wo;
     const long M = (long)g.B * RH * RW;
     const long m0 = (long)blockIdx.x * BM;
-    const int ntaps = g.KH * g.KW, nchunks = ntaps * CPT;
+    const int ntaps = g.KH * g.KW;
+    // Pixel-major rows (g.pmajor, small maps): the rows of a block then share ONE pixel position (two where a block straddles a
+    // boundary), so the taps that fall into the padding for that position are known per block and their chunks are skipped
+    // altogether -- on conv4's 3 x 2 map 48 % of all (pixel, tap) pairs are padding, on conv3's 4 x 3 output 35 %.  Clip-major rows
+    // mix all positions in every block and multiply those zeros.  taps: the block's tap list, four bits each.
+    const int P = RH * RW;
+    const bool pm = g.pmajor != 0;
+    auto row_of = [&](long q, int &b, int &pix) {      // logical row q -> (clip, pixel); M < 2^31 (checked by the launcher): 32-bit divisions
+        const unsigned qq = (unsigned)q;
+        if (pm) { pix = (int)(qq / (unsigned)g.B); b = (int)(qq - (unsigned)pix * (unsigned)g.B); }
+        else { b = (int)(qq / (unsigned)P); pix = (int)(qq - (unsigned)b * (unsigned)P); }
+    };
+    unsigned long long taps = 0ull;
+    int ntv = ntaps;
+    if (pm) {
+        const long qe = m0 + BM - 1 < M - 1 ? m0 + BM - 1 : M - 1;
+        const int p_lo = (int)(m0 / g.B), p_hi = (int)(qe / g.B);
+        ntv = 0;
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int kh = tap / g.KW, kw = tap % g.KW;
+            bool any = false;
+            for (int pp = p_lo; pp <= p_hi; ++pp) {
+                const int y = pp / RW, x = pp % RW;
+                const int sy = MODE == MODE_FWD ? y * g.stride + kh - g.pt : y + g.pt - kh;
+                const int sx = MODE == MODE_FWD ? x * g.stride + kw - g.pl : x + g.pl - kw;
+                any = any || (sy >= 0 && sy < SH && sx >= 0 && sx < SW);
+            }
+            if (any) { taps |= (unsigned long long)tap << (4 * ntv); ++ntv; }
+        }
+    }
+    const int nchunks = ntv * CPT;
 
     int a_b[NAU], a_y[NAU], a_x[NAU];         // per-thread A-staging coordinates: row = u / UPR, piece = u % UPR
 #pragma unroll
@@ -256,8 +288,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
         const int u = tid + 256 * j;
         const long m = m0 + u / UPR;
         if (m < M) {
-            const int pix = (int)(m % ((long)RH * RW));
-            a_b[j] = (int)(m / ((long)RH * RW));
+            int pix;
+            row_of(m, a_b[j], pix);
             a_y[j] = pix / RW;
             a_x[j] = pix % RW;
         } else {
@@ -268,7 +300,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector type: HIP's uint4 struct kept these arrays in scratch
     struct Staged { f32x4 a[APRE ? 1 : NAU]; u32x4 ap[APRE ? 3 : 1][NAU]; u32x4 b[3][NBU]; };
     auto load_chunk = [&](int chunk, Staged &st) {
-        const int tap = chunk / CPT, c0 = (chunk % CPT) * KC;
+        const int ti = chunk / CPT, c0 = (chunk % CPT) * KC;
+        const int tap = pm ? (int)((taps >> (4 * ti)) & 15ull) : ti;
         const int kh = tap / g.KW, kw = tap % g.KW;
 #pragma unroll
         for (int j = 0; j < NAU; ++j) {
@@ -359,6 +392,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
         }
     }
 
+    long mrow[RT][4];                                  // the NHWC row of each of this lane's accumulator rows, -1 past the end
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long q = m0 + 16 * (wm * RT + rt) + 4 * lq + r;
+            long m = q < M ? q : -1;
+            if (pm && q < M) {
+                int b, pix;
+                row_of(q, b, pix);
+                m = (long)b * P + pix;
+            }
+            mrow[rt][r] = m;
+        }
     float ssum[CT], ssq[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -373,8 +420,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const long m = m0 + 16 * (wm * RT + rt) + 4 * lq + r;
-                if (m < M) {
+                const long m = mrow[rt][r];
+                if (m >= 0) {
                     float v = acc[rt][c][r];
                     if (EPI == EPI_RELU) v = fmaxf(v, 0.f);
                     if (EPI == EPI_BIAS_RELU6) v = relu6f(v + bv);

@@ -284,10 +284,18 @@ static inline int infer_prec(const kws_model *m) { return m->infer_precision >= 
 
 // returns the number of blocks that wrote BatchNorm partial sums (0: `partial` was not given or the grid exceeds its stride)
 template <int CR, int CO, int MODE, int EPI>
-int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], const float *bias, float *dst, const ConvGeom &g,
+int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], const float *bias, float *dst, const ConvGeom &g_in,
                 hipStream_t s, double *partial = nullptr, const float *shift = nullptr, __bf16 *const *src_planes = nullptr)
 {
+    ConvGeom g = g_in;
     const long M = MODE == MODE_FWD ? (long)g.B * g.Ho * g.Wo : (long)g.B * g.H * g.W;
+    if (M >= (1L << 31)) return fail(KWS_ERR_UNSUPPORTED, "%s: %ld rows exceed the kernel's 32-bit row index", what, M);
+    {
+        // small maps with 'same' padding: pixel-major rows let a block skip the taps that are padding for its position (kws_conv.h)
+        const int P = MODE == MODE_FWD ? g.Ho * g.Wo : g.H * g.W;
+        static const bool off = getenv("KWS_NO_PMAJOR") != nullptr;
+        g.pmajor = (!off && g.KH == 3 && g.KW == 3 && P > 1 && P <= 16) ? 1 : 0;
+    }
     static const std::string name = std::string(what) + "<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
     const int o = MODE == MODE_FWD ? 3 : 0;      // forward reads the transposed planes, the data gradient the original order
     const Bf16Planes wp{{planes[o], planes[o + 1], planes[o + 2]}};

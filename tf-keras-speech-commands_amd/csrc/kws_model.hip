@@ -531,8 +531,10 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     // Dense(128, use_bias=True) + ReLU6 as a (H4 x W4) 'valid' convolution over the pooled map (Flatten is h,w,c)
     ConvGeom g;
     g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
+    if (hook) KWS_TRY(hook->fire(6, s));
     if (bf16) KWS_TRY_NB(launch_bf16<128, 128, MODE_FWD, EPI_BIAS_RELU6>("conv_bf16_fwd", w.a[3], w.wsp[2], params + m->o_db, w.d1, g, s));
     else KWS_TRY(launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s));
+    if (hook) KWS_TRY(hook->fire(7, s));
     KWS_LAUNCH_CHECK("simple_cnn forward");
     return KWS_OK;
 }
@@ -1280,7 +1282,16 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     // backward 0.760, behind conv4's data gradient 0.727
     OverlapHook hook;
     hook.ev = static_cast<hipEvent_t>(a->overlap_event); hook.cb = a->overlap_callback; hook.user = a->overlap_user;
-    hook.at = lite ? 1 : 0;
+    // simple_cnn: behind the head's backward kernel, in front of the dense weight gradient's fork.  Same-box sweep with the round-2 kernels
+    // (ms per step at B = 4096): behind conv4's forward 0.692-0.697 (the choice until then: the featurizer ran beside the dense / head
+    // kernels and doubled their time), behind BatchNorm-4's activation 0.690, behind the dense forward 0.714, behind the forward pass
+    // 0.729, here 0.686, behind the dense data gradient 0.704, behind BatchNorm-4's backward 0.721, behind conv4's data gradient 0.699.
+    // KWS_OVERLAP_AT = 0 .. 7 re-runs the sweep.
+    hook.at = lite ? 1 : 2;
+    {
+        static const char *ov = getenv("KWS_OVERLAP_AT");
+        if (ov && !lite) hook.at = atoi(ov);
+    }
     rc = lite ? lite_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s)
               : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s, a->grads, &grads_zeroed, &hook, a->feat_moments);
     if (rc) return rc;

@@ -251,7 +251,7 @@ class DeviceModel(object):
         a.forward_event = forward_event.cuda_event if forward_event is not None else None
         a.overlap_event = overlap_event.cuda_event if overlap_event is not None else None
         raised = []
-        if overlap_callback is not None:           # host function called behind the last forward convolution (see include/kws.h)
+        if overlap_callback is not None:           # host function called at the step's overlap point (see include/kws.h)
             def _cb(_user):
                 try:
                     overlap_callback()

@@ -62,6 +62,22 @@ bool prof_on();
 const char *prof_name(const char *base, int layer);   // interned "<base>.L<layer>" while profiling, else base
 void prof_events(const char *name, hipEvent_t *e0, hipEvent_t *e1);   // a fresh pair, remembered under `name`
 
+// Fork events without a marker packet.  hipEventRecord on the caller's stream puts a barrier packet of its own between two kernels of the
+// main chain, and every such packet cost the chain 6-8 us (rocprofv3 timeline: five forks / joins per train step).  A kernel launched
+// through hipExtLaunchKernel can carry a stop event that is bound to the dispatch's own completion signal instead: arm_stop_event(ev, s)
+// makes the NEXT kernel launched on s carry ev; fork code then only lets the other stream wait for ev (stop_event_bound tells whether the
+// launch took it; if no kernel followed, the caller records the event the plain way).  One armed event per host thread.
+struct ArmedEvent { hipEvent_t ev = nullptr; hipStream_t s = nullptr; hipEvent_t bound = nullptr; };
+ArmedEvent &armed_event();
+inline void arm_stop_event(hipEvent_t ev, hipStream_t s) { ArmedEvent &a = armed_event(); a.ev = ev; a.s = s; a.bound = nullptr; }
+inline bool stop_event_bound(hipEvent_t ev)      // true: the kernel launched since arm_stop_event carries ev (consumes the answer)
+{
+    ArmedEvent &a = armed_event();
+    const bool yes = a.bound == ev && ev != nullptr;
+    a.ev = nullptr; a.bound = nullptr;
+    return yes;
+}
+
 template <size_t I, typename Tuple>
 inline void set_launch_args(Tuple &) {}
 template <size_t I, typename Tuple, typename A, typename... Rest>
@@ -82,6 +98,22 @@ inline void launch_timed_impl(const char *name, void (*kernel)(KArgs...), dim3 g
     prof_events(name, &e0, &e1);
     (void)hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, smem, s, e0, e1, 0);
 }
+// the same launch with a stop event and no timing pair (fork events, see ArmedEvent)
+template <typename... KArgs, typename... Args, size_t... I>
+inline void launch_stop_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t s, hipEvent_t stop,
+                             std::index_sequence<I...>, Args &&...args)
+{
+    std::tuple<std::remove_cv_t<KArgs>...> vals{};
+    set_launch_args<0>(vals, std::forward<Args>(args)...);
+    void *ptrs[sizeof...(KArgs) + 1] = {static_cast<void *>(&std::get<I>(vals))..., nullptr};
+    (void)hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, smem, s, nullptr, stop, 0);
+}
+template <typename... KArgs, typename... Args>
+inline void launch_stop(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t s, hipEvent_t stop, Args &&...args)
+{
+    static_assert(sizeof...(Args) <= sizeof...(KArgs), "argument count of a kernel launch");
+    launch_stop_impl(kernel, grid, block, smem, s, stop, std::index_sequence_for<KArgs...>{}, std::forward<Args>(args)...);
+}
 template <typename... KArgs, typename... Args>
 inline void launch_timed(const char *name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t s, Args &&...args)
 {
@@ -93,6 +125,11 @@ inline void launch_timed(const char *name, void (*kernel)(KArgs...), dim3 grid, 
 
 #define KWS_LAUNCH(name, kernel, grid, block, smem, stream, ...)                                              \
     do {                                                                                                     \
+        ::kws::ArmedEvent &ae__ = ::kws::armed_event();                                                      \
         if (::kws::prof_on()) ::kws::launch_timed(name, kernel, dim3(grid), dim3(block), smem, stream, __VA_ARGS__); \
-        else hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                             \
+        else if (ae__.ev && ae__.s == (stream)) {                                                            \
+            ::kws::launch_stop(kernel, dim3(grid), dim3(block), smem, stream, ae__.ev, __VA_ARGS__);         \
+            ae__.bound = ae__.ev;                                                                            \
+            ae__.ev = nullptr;                                                                               \
+        } else hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                           \
     } while (0)

@@ -56,6 +56,12 @@ const char *prof_name(const char *base, int layer)
     return interned.emplace(key, key).first->second.c_str();
 }
 
+ArmedEvent &armed_event()
+{
+    static thread_local ArmedEvent a;
+    return a;
+}
+
 void prof_events(const char *name, hipEvent_t *e0, hipEvent_t *e1)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);

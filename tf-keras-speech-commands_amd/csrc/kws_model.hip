@@ -36,11 +36,13 @@ struct OverlapHook {
     void *user = nullptr;
     int at = 0;
     bool fired = false;
-    int fire(int point, hipStream_t s)
+    bool wants(int point) const { return !fired && point == at; }
+    // already_bound: the event rides on the completion signal of the last kernel launched on s (kws_common.h: ArmedEvent)
+    int fire(int point, hipStream_t s, bool already_bound = false)
     {
         if (fired || point != at) return KWS_OK;
         fired = true;
-        if (ev) KWS_HIP_CHECK(hipEventRecord(ev, s));
+        if (ev && !already_bound) KWS_HIP_CHECK(hipEventRecord(ev, s));
         if (cb) cb(user);
         return KWS_OK;
     }
@@ -559,8 +561,14 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     hipStream_t s2 = R->side;
     const int mprec = matrix_prec(m);
     const bool det = m->deterministic != 0;
-    auto fork = [&](int ev) -> int {          // side stream waits for everything enqueued on s so far
-        KWS_HIP_CHECK(hipEventRecord(R->ev[ev], s));
+    // fork: the side stream waits for everything enqueued on s so far.  arm(ev) in front of the LAST kernel before the fork lets that
+    // kernel's own completion signal be the event (kws_common.h: ArmedEvent) instead of a marker packet on the main chain
+    static const bool no_arm = getenv("KWS_NO_ARMED_EVENTS") != nullptr;
+    hipEvent_t fork0_ev = nullptr;
+    bool fork0_bound = false;
+    auto arm = [&](int ev) { if (!no_arm) arm_stop_event(R->ev[ev], s); };
+    auto fork = [&](int ev) -> int {
+        if (!stop_event_bound(R->ev[ev])) KWS_HIP_CHECK(hipEventRecord(R->ev[ev], s));
         KWS_HIP_CHECK(hipStreamWaitEvent(s2, R->ev[ev], 0));
         return KWS_OK;
     };
@@ -568,17 +576,28 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     {
         // the MFMA head kernel also leaves the dense bias gradient (column sums of dd1) and the loss / accuracy sums
         const bool fuse = head_bwd_fuses(m);
+        // the head's backward kernel is the last one in front of the dense fork AND of overlap point 2: its completion signal carries the
+        // caller's overlap event when there is one (the side stream then waits for that event too), the fork event otherwise
+        // (deterministic mode launches two kernels here and keeps the recorded events)
+        fork0_ev = (hook && hook->wants(2) && hook->ev) ? hook->ev : R->ev[0];
+        if (!det && !no_arm) arm_stop_event(fork0_ev, s);
         KWS_TRY(run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s, fuse && !det ? grads + m->o_db : nullptr, w.loss_i, w.correct_i,
                              fuse ? stats : nullptr, det));
+        fork0_bound = stop_event_bound(fork0_ev);
     }
     // dense 256->128: bias grad (column sums), wgrad, dgrad -> da4 (gradient w.r.t. the dropped, flattened map)
     {
         ConvGeom g;
         g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
-        if (hook) KWS_TRY(hook->fire(2, s));
-        // its own fork, although every event costs the main chain 6-8 us: started later, together with conv4's weight
-        // gradient, the step was 2 % slower (same-box A/B)
-        if (int rc = fork(0)) return rc;
+        const bool hook_ev_here = hook && hook->wants(2) && hook->ev;
+        if (hook) KWS_TRY(hook->fire(2, s, fork0_bound && hook_ev_here));
+        // its own fork: started later, together with conv4's weight gradient, the step was 2 % slower (same-box A/B)
+        if (hook_ev_here) {
+            KWS_HIP_CHECK(hipStreamWaitEvent(s2, fork0_ev, 0));       // the overlap event (recorded or bound just above) is the fork event
+        } else {
+            if (!fork0_bound) KWS_HIP_CHECK(hipEventRecord(R->ev[0], s));
+            KWS_HIP_CHECK(hipStreamWaitEvent(s2, R->ev[0], 0));
+        }
         KWS_TRY(launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s2, det));
         int nblk, rows;
         stat_grid(B, 128, nblk, rows);
@@ -620,8 +639,12 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         else
             KWS_LAUNCH(prof_name("bn_bwd_reduce_kernel", l + 1), bn_bwd_reduce_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l], da, k, w.gz[l], B, Hz[l], Wz[l], C,
                        rows, w.partial, rate, slo, shi);
+        // conv2's early weight gradient forks right behind this finalize kernel
+        const bool wgrad_early_l1 = compact_g && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
+        if (l == 1 && wgrad_early_l1) arm(1);
         KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
                    grads + m->o_g[l], grads + m->o_b[l], k);
+        if (l != 1) arm(l);                                 // the apply kernel below is the last one in front of fork(l)
         if (l == 1)
             ;                                                   // fused into conv_dgrad_clip's staging below
         else if (l == 3 && mprec == 1)
@@ -689,6 +712,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (wgrad_early) {
                 if (int rc = fork(1)) return rc;
                 static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel<true>, 256, smwb);
+                if (!no_arm) arm_stop_event(R->ev[9], s2);       // the last kernel of the side stream: its completion is the join event
                 KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel<true>, wgrad_grid(occ), dim3(256), smwb, s2, in, nullptr, dk, B, H1, W1, bn);
             }
             if (mprec == 1) {
@@ -749,7 +773,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                        grads + m->o_k[0], B, d.H0, d.W0, det ? B : cpb);
         }
     }
-    KWS_HIP_CHECK(hipEventRecord(R->ev[9], s2));             // join: every wgrad is part of the caller's stream order again
+    if (!stop_event_bound(R->ev[9])) KWS_HIP_CHECK(hipEventRecord(R->ev[9], s2));   // join: every wgrad is part of the caller's stream order again
     KWS_HIP_CHECK(hipStreamWaitEvent(s, R->ev[9], 0));
     KWS_LAUNCH_CHECK("simple_cnn backward");
     return KWS_OK;

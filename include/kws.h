@@ -214,10 +214,9 @@ typedef struct kws_train_args {
                                    featurization) can be ordered after it                                       */
     void *overlap_event;        /* NULL or a hipEvent_t recorded on `stream` at the best point of the step to start independent
                                    vector-ALU / memory work on another stream (the next batch's featurization).  simple_cnn: behind
-                                   the head's backward kernel, in front of the dense weight gradient (same-box sweep of eight points
-                                   at B = 4096: 0.686 ms per step there, 0.692-0.697 behind the last forward convolution, 0.729
-                                   at forward_event; kws_model.hip); simple_cnn_lite and the recurrent models record it
-                                   together with forward_event.                                                         */
+                                   the last BatchNormalization's activation kernel, in front of the dense layer (sweeps of eight points
+                                   at B = 4096 on four boxes: 0.681-0.691 ms per step there, 0.729 at forward_event; kws_model.hip);
+                                   simple_cnn_lite and the recurrent models record it together with forward_event.          */
     void (*overlap_callback)(void *user);   /* NULL or a host function the call invokes (same thread, once) right after it has
                                    enqueued the work overlap_event marks: enqueueing the next batch's kws_featurize from it
                                    puts that launch at the same place in HOST order, so the overlap does not depend on how far

@@ -455,6 +455,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         else KWS_LAUNCH("l1_act_pool_kernel", l1_act_pool_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
                    d.H0, d.W0, cpb);
     }
+    bool bound6 = false;
     for (int l = 1; l < 4; ++l) {
         const float *in = w.a[l - 1];
         const float *kern = params + m->o_k[l];
@@ -520,6 +521,10 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         // behind the last convolution: from here to BN4's backward the main chain is small kernels (activation, dense, head),
         // the best place for the caller to start the next batch's featurizer (kws_train_args.overlap_event)
         if (l == 3 && hook) KWS_TRY(hook->fire(0, s));
+        // overlap point 6 sits right behind this layer's activation kernel: the caller's event rides on that kernel's completion signal
+        // instead of a marker packet of its own (kws_common.h: ArmedEvent)
+        const bool arm6 = l == 3 && hook && hook->wants(6) && hook->ev && getenv("KWS_NO_ARMED_EVENTS") == nullptr;
+        if (arm6) arm_stop_event(hook->ev, s);
         if (pool[l]) {
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
@@ -529,11 +534,12 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
                                w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
         }
+        if (arm6) bound6 = stop_event_bound(hook->ev);
     }
     // Dense(128, use_bias=True) + ReLU6 as a (H4 x W4) 'valid' convolution over the pooled map (Flatten is h,w,c)
     ConvGeom g;
     g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
-    if (hook) KWS_TRY(hook->fire(6, s));
+    if (hook) KWS_TRY(hook->fire(6, s, bound6));
     if (bf16) KWS_TRY_NB(launch_bf16<128, 128, MODE_FWD, EPI_BIAS_RELU6>("conv_bf16_fwd", w.a[3], w.wsp[2], params + m->o_db, w.d1, g, s));
     else KWS_TRY(launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s));
     if (hook) KWS_TRY(hook->fire(7, s));
@@ -1306,12 +1312,13 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     // backward 0.760, behind conv4's data gradient 0.727
     OverlapHook hook;
     hook.ev = static_cast<hipEvent_t>(a->overlap_event); hook.cb = a->overlap_callback; hook.user = a->overlap_user;
-    // simple_cnn: behind the head's backward kernel, in front of the dense weight gradient's fork.  Same-box sweep with the round-2 kernels
-    // (ms per step at B = 4096): behind conv4's forward 0.692-0.697 (the choice until then: the featurizer ran beside the dense / head
-    // kernels and doubled their time), behind BatchNorm-4's activation 0.690, behind the dense forward 0.714, behind the forward pass
-    // 0.729, here 0.686, behind the dense data gradient 0.704, behind BatchNorm-4's backward 0.721, behind conv4's data gradient 0.699.
-    // KWS_OVERLAP_AT = 0 .. 7 re-runs the sweep.
-    hook.at = lite ? 1 : 2;
+    // simple_cnn: behind BatchNorm-4's activation kernel, in front of the dense forward product.  Same-box sweeps with the round-2 kernels
+    // (ms per step at B = 4096, four different boxes): behind conv4's forward 0.679-0.697, HERE 0.681-0.691 (never worse than the former,
+    // usually 2-6 us better), behind the dense forward 0.714, behind the forward pass 0.729, behind the dense data gradient 0.704, behind
+    // BatchNorm-4's backward 0.721, behind conv4's data gradient 0.699.  Behind the head's backward kernel (point 2) was the best point on two
+    // boxes (0.686) and the worst on two others (0.709-0.722, whatever the hardware-queue count): the featurizer then starts together with
+    // the side stream's weight-gradient chain, and which of the two gets the chip first decides.  KWS_OVERLAP_AT = 0 .. 7 re-runs the sweep.
+    hook.at = lite ? 1 : 6;
     {
         static const char *ov = getenv("KWS_OVERLAP_AT");
         if (ov && !lite) hook.at = atoi(ov);

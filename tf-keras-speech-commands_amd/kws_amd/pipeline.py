@@ -36,8 +36,8 @@ class FeaturePipeline(object):
     def submit(self, wav, valid_len=None, after=None):
         """Enqueue the featurization of one batch on the side stream (returns at once).  `after`: an event on the main
         stream to start behind -- best the running step's overlap_event (DeviceModel.train_fwd_bwd(overlap_event=...),
-        recorded at the point of the step that a sweep found best for this -- for simple_cnn behind the head's backward
-        kernel, include/kws.h); call submit from train_fwd_bwd's overlap_callback so that the launch also
+        recorded at the point of the step that a sweep found best for this -- for simple_cnn behind the last
+        BatchNormalization's activation kernel, include/kws.h); call submit from train_fwd_bwd's overlap_callback so that the launch also
         sits there in host order; default: everything enqueued so far."""
         torch = _torch()
         i = self.n_submitted % 2

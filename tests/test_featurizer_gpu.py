@@ -249,3 +249,24 @@ def test_feature_pipeline_matches_direct_calls(torch):
     torch.cuda.synchronize()
     for got, w in zip(seen, want):
         assert torch.equal(got, w)
+
+
+@pytest.mark.parametrize("bank", ["mel", "bark"])
+def test_shared_mode_kernel_equals_standalone(torch, bank):
+    """kws_featurizer_set_cu_share(f, 1) selects the form of the tuned kernel that keeps its twiddles in registers (one block per CU beside
+    a train step): same arithmetic, so the features equal the stand-alone form bit for bit -- float32 and PCM16 input, ragged lengths
+    (left-padded clips take the masked load path), a batch that does not divide over the grid's waves."""
+    from classifier.params import pr
+    from kws_amd.featurizer import Featurizer
+    B = 333
+    rng = np.random.default_rng(21)
+    a = np.clip(0.2 * rng.standard_normal((B, 16000)), -1, 1 - 2.0 ** -15).astype(np.float32)
+    lens = rng.integers(3000, 16001, B).astype(np.int32)
+    lens[::7] = 16000
+    wav, vl = torch.from_numpy(a).cuda(), torch.from_numpy(lens).cuda()
+    w16 = torch.from_numpy((a * 32768).astype(np.int16)).cuda()
+    alone, shared = Featurizer(pr, bank), Featurizer(pr, bank)
+    shared.set_cu_share(1)
+    for x in (wav, w16):
+        assert torch.equal(alone(x, vl), shared(x, vl))
+        assert torch.equal(alone(x), shared(x))

@@ -615,16 +615,17 @@ static bool v2_applies(const FeatDev &d)
     return !disabled && d.n_fft == 1024 && d.hop == 512 && d.window_eff == 1024 && !d.use_delta && d.n_filt == kV2Bands &&
            d.n_out == kV2Coefs && (d.chp2 == 12 || d.chp2 == 16 || d.chp2 == 20);
 }
-static size_t v2_smem_bytes(int chp)
+static size_t v2_smem_bytes(int chp, int waves = kV2Waves)
 {
     constexpr int TB = 64 / kV2Bands;
-    return (size_t)kV2Waves * (kFftTile * 8 + 4 * (TB * 64 + 64 + 4)) + 4 * (size_t)(kV2Bands * kV2Coefs + 64 * chp) +
+    return (size_t)waves * (kFftTile * 8 + 4 * (TB * 64 + 64 + 4)) + 4 * (size_t)(kV2Bands * kV2Coefs + 64 * chp) +
            8 * (size_t)(7 * 64 + 7 * 8 + 4 * 64) + 4 * (size_t)round4(kV2Bands + 1);
 }
-template <typename WavT, int CHP>
+template <typename WavT, int CHP, int WAVES = kV2Waves, bool TWREG = false>
 static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s,
                      const char *name)
 {
+    constexpr int kV2Waves = WAVES;          // shadows the default: everything below is per configuration
     // persistent grid: two 12-wave blocks per CU; frames per job chosen so that the jobs divide evenly over the grid's waves
     static const int cus = [] {
         int dev = 0;
@@ -634,8 +635,8 @@ static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, c
         return 256;
     }();
     static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem_bytes(CHP));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs, WAVES, TWREG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem_bytes(CHP, WAVES));
         return true;
     }();
     (void)attr;
@@ -655,8 +656,8 @@ static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, c
     }
     const long jobs = (long)B * dd.jpc;
     const unsigned grid = (unsigned)std::min<long>((long)bpc * cus, (jobs + kV2Waves - 1) / kV2Waves);
-    KWS_LAUNCH(name, (featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs>), dim3(grid), dim3(kV2Waves * 64), v2_smem_bytes(CHP), s, wav,
-               stride, valid_len, B, dd, feat);
+    KWS_LAUNCH(name, (featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs, WAVES, TWREG>), dim3(grid), dim3(kV2Waves * 64),
+               v2_smem_bytes(CHP, WAVES), s, wav, stride, valid_len, B, dd, feat);
     KWS_LAUNCH_CHECK("featurize_fft1024_v2_kernel");
     return KWS_OK;
 }
@@ -664,6 +665,13 @@ template <typename WavT>
 static int launch_v2_chp(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s,
                          const char *name)
 {
+    // Sharing the chip with a train step (kws_featurizer_set_cu_share(f, 1): one 12-wave block per CU) the kernel keeps its per-lane
+    // twiddles in registers: 18 of its ~87 LDS instructions per frame go away, which the step's LDS-staged kernels beside it feel more than
+    // the featurizer itself (same-box A/B at B = 4096: step 0.674-0.684 -> 0.663-0.671 ms, the featurizer alone 0.115 -> 0.107 ms).  With
+    // the chip to itself (two blocks per CU) the 120 registers of that form allow only 16 waves per CU; measured as 2 x 8 waves it equals
+    // the LDS-twiddle form at 24 waves (featurize + forward 0.2846 vs 0.2848 ms), so the stand-alone configuration stays as it was.
+    if (d.blocks_per_cu == 1 && d.chp2 == 20) return launch_v2<WavT, 20, kV2Waves, true>(d, wav, B, stride, valid_len, feat, s, name);
+    if (d.blocks_per_cu == 1 && d.chp2 == 16) return launch_v2<WavT, 16, kV2Waves, true>(d, wav, B, stride, valid_len, feat, s, name);
     switch (d.chp2) {
     case 12: return launch_v2<WavT, 12>(d, wav, B, stride, valid_len, feat, s, name);
     case 16: return launch_v2<WavT, 16>(d, wav, B, stride, valid_len, feat, s, name);

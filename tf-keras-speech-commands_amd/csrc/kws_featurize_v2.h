@@ -111,10 +111,14 @@ template <> __device__ __forceinline__ void gather_chunk<20>(float &part, unsign
 
 constexpr int kV2Waves = 12;          // waves per block: 2 blocks per CU = 24 waves = 6 per SIMD (<= 80 VGPRs), the filter / twiddle tables twice per CU
 
-template <typename WavT, int CHP, int NF, int NO>
-__global__ __launch_bounds__(kV2Waves * 64, 6) void featurize_fft1024_v2_kernel(const WavT *__restrict__ wav, int64_t stride,
-                                                                         const int32_t *__restrict__ valid_len, int B,
-                                                                         FeatDev c, float *__restrict__ feat)
+// WAVES: waves per block.  TWREG: the per-lane twiddles of the three passes and of the real-FFT split (7 + 7 + 4 complex values that
+// never change for a lane) live in 36 registers instead of being re-read from LDS for every frame -- 18 of the ~87 LDS instructions
+// per frame, in a kernel that is bound by LDS issue.  It costs occupancy (116 instead of 80 registers: 4 instead of 6 waves per SIMD),
+// so which form runs is the launcher's choice (kws_featurize.hip: launch_v2).
+template <typename WavT, int CHP, int NF, int NO, int WAVES = kV2Waves, bool TWREG = false>
+__global__ __launch_bounds__(WAVES * 64, TWREG ? 4 : 6) void featurize_fft1024_v2_kernel(const WavT *__restrict__ wav, int64_t stride,
+                                                                                  const int32_t *__restrict__ valid_len, int B,
+                                                                                  FeatDev c, float *__restrict__ feat)
 {
     static_assert(NF % 4 == 0 && NF <= 32 && NO <= NF && CHP % 4 == 0, "band / coefficient counts of the tuned kernel");
     constexpr int TB = 64 / NF;                       // frames per tail batch (lanes = frame x band)
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(kV2Waves * 64, 6) void featurize_fft1024_v2_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int kWaves = kV2Waves, kThreads = kV2Waves * 64;
+    constexpr int kWaves = WAVES, kThreads = WAVES * 64;
 
     float2 *s_fft = reinterpret_cast<float2 *>(smem) + wave * kFftTile;
     float *s_pw = reinterpret_cast<float *>(s_fft);                       // power spectrum aliases the FFT tile
@@ -157,6 +161,15 @@ __global__ __launch_bounds__(kV2Waves * 64, 6) void featurize_fft1024_v2_kernel(
     const unsigned a_x1 = lds_addr(s_fft + 72 * hi + lo), a_x2 = lds_addr(s_fft + 72 * hi + 9 * lo);
     const unsigned a_pw = lds_addr(s_pw + (chunk_pack & 0xFFFF)), a_w = lds_addr(s_w + lane * CHP);
 
+    f32x2 tw1r[TWREG ? 7 : 1], tw2r[TWREG ? 7 : 1], twsr[TWREG ? 4 : 1];
+    if constexpr (TWREG) {
+        LdsRow<7, 64 * 8>::template go<0>(tw1r, a_tw1);
+        LdsRow<7, 8 * 8>::template go<0>(tw2r, a_tw2);
+        LdsRow<4, 64 * 8>::template go<0>(twsr, a_tws);
+        lds_wait(tw1r);
+        lds_wait(tw2r);
+        lds_wait(twsr);
+    }
     // Persistent waves: a JOB = c.fpw consecutive frames of one clip; the jobs of the batch are dealt round-robin to the
     // grid's waves (the tables above are loaded once per block, not once per clip, and no block waits for a launch slot).
     const int njobs = B * c.jpc;
@@ -195,9 +208,12 @@ __global__ __launch_bounds__(kV2Waves * 64, 6) void featurize_fft1024_v2_kernel(
         // pass 1: DFT-8 over n1 (n = lane + 64 n1), twiddle W_512^(lane*k1)
         {
             f32x2 tw[7];
-            LdsRow<7, 64 * 8>::template go<0>(tw, a_tw1);      // issued ahead of the butterflies that hide their latency
+            if constexpr (!TWREG) LdsRow<7, 64 * 8>::template go<0>(tw, a_tw1);      // issued ahead of the butterflies that hide their latency
             dft8(v);
-            lds_wait(tw);
+            if constexpr (TWREG) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) tw[k] = tw1r[k];
+            } else lds_wait(tw);
 #pragma unroll
             for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], make_float2(tw[k - 1].x, tw[k - 1].y));
         }
@@ -208,13 +224,19 @@ __global__ __launch_bounds__(kV2Waves * 64, 6) void featurize_fft1024_v2_kernel(
         {
             f32x2 t[8], tw[7];
             LdsRow<8, 8 * 8>::template go<0>(t, a_x1);         // s_fft[72 hi + lo + 8 j]
-            LdsRow<7, 8 * 8>::template go<0>(tw, a_tw2);       // s_tw2[(k - 1) * 8 + lo]
-            lds_wait<7>(t);
+            if constexpr (TWREG) lds_wait<0>(t);
+            else {
+                LdsRow<7, 8 * 8>::template go<0>(tw, a_tw2);   // s_tw2[(k - 1) * 8 + lo]
+                lds_wait<7>(t);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = make_float2(t[j].x, t[j].y);
             // pass 2: lane = (k1, l2); DFT-8 over l1, twiddle W_64^(l2*k2a)
             dft8(v);
-            lds_wait(tw);
+            if constexpr (TWREG) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) tw[k] = tw2r[k];
+            } else lds_wait(tw);
 #pragma unroll
             for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], make_float2(tw[k - 1].x, tw[k - 1].y));
         }
@@ -226,8 +248,11 @@ __global__ __launch_bounds__(kV2Waves * 64, 6) void featurize_fft1024_v2_kernel(
         {
             f32x2 t[8];
             LdsRow<8, 8>::template go<0>(t, a_x2);             // s_fft[72 hi + 9 lo + j]
-            LdsRow<4, 64 * 8>::template go<0>(tws, a_tws);     // W_1024^(ka + 64 i), used by the split below
-            lds_wait<4>(t);
+            if constexpr (TWREG) lds_wait<0>(t);
+            else {
+                LdsRow<4, 64 * 8>::template go<0>(tws, a_tws); // W_1024^(ka + 64 i), used by the split below
+                lds_wait<4>(t);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = make_float2(t[j].x, t[j].y);
         }
@@ -248,7 +273,10 @@ __global__ __launch_bounds__(kV2Waves * 64, 6) void featurize_fft1024_v2_kernel(
         }
         // real-FFT split: X[k] = E[k] + W_1024^k O[k], X[512-k] = conj(E[k] - W_1024^k O[k])
         float pk[4], pm[4], energy = 0.f;
-        lds_wait(tws);
+        if constexpr (TWREG) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tws[i] = twsr[i];
+        } else lds_wait(tws);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float2 zk = v[i], zq = zm[i];

@@ -9,6 +9,9 @@
 //   l1_bwd_reduce_kernel sum g, sum g*xhat from da1 (pool/ReLU6 masks)  (backward)
 //   l1_bwd_wgrad_kernel  dz = k1 (g - k2 - xhat k3); dW1 += x (*) dz     (backward; dz never leaves registers)
 // The same device function produces z everywhere, so the ReLU6 / arg-max decisions agree bit for bit between passes.
+// These per-thread kernels serve odd map sizes.  Even maps run on the fp32 MFMA, one wave per clip: the forward kernels further down
+// (l1m_act_pool_kernel for inference, L1Mma / l1f_forward_clips shared with the training kernel) and, for training, the second-moment
+// form of kws_layer1_moments.h (statistics and gradients in closed form, ONE backward pass: kws_layer1_fast.h for the default map).
 #pragma once
 #include "kws_layers.h"
 
@@ -345,21 +348,6 @@ __device__ __forceinline__ void l1m_route(const f32x4 &z, float sc, float sh, fl
     }
     const float ya = arg == 0 ? y[0] : arg == 1 ? y[1] : arg == 2 ? y[2] : y[3];
     g = (ya > 0.f && ya < 6.f) ? da : 0.f;
-}
-
-// block-level reduction of two per-lane double sums that belong to channel li: over lq in the wave, then over the 4 waves
-__device__ __forceinline__ void l1m_reduce_store(double s0, double s1, double *__restrict__ partial)
-{
-    __shared__ double red[4][2][16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
-    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
-    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-    if (lq == 0) { red[wave][0][li] = s0; red[wave][1][li] = s1; }
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        const int which = threadIdx.x >> 4, c = threadIdx.x & 15;
-        partial[((long)which * 16 + c) * kStatStride + blockIdx.x] = (red[0][which][c] + red[1][which][c]) + (red[2][which][c] + red[3][which][c]);
-    }
 }
 
 // Forward body (conv1 -> BN -> ReLU6 -> 2x2 max) for a compile-time map size, shared by the training and the inference kernel.  The

@@ -222,12 +222,17 @@ struct Bf16Planes { const __bf16 *p[3]; };
 // double) to partial[(which*CO + n)*partial_stride + blockIdx.x], which replaces a separate pass over the conv output.
 // APRE: the A operand arrives already split (planes `ap` in the layout of `src`, which is then unused): staging copies 16-byte
 // pieces (one unit = 8 channels of a row) instead of splitting -- nine taps re-stage every row, so the split was done nine times.
-template <int CR, int CO, int MODE, int EPI, int RT, bool STATS = false, bool APRE = false>
+// ABN: `src` is the PRE-activation tensor z of the BatchNormalization -> ReLU6 in front of this convolution and abn = its scale[CR] |
+// shift[CR]: the activation a = relu6(z * scale + shift) is formed while the rows are staged (two vector instructions per element) and is
+// never written to memory -- for a layer without pooling this replaces the activation kernel and its tensor.  Padding rows stay zero.
+template <int CR, int CO, int MODE, int EPI, int RT, bool STATS = false, bool APRE = false, bool ABN = false>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restrict__ src, Bf16Planes wp, const float *__restrict__ bias,
                                                          float *__restrict__ dst, ConvGeom g, double *__restrict__ partial = nullptr,
                                                          int partial_stride = 0, const float *__restrict__ shift = nullptr,
-                                                         Bf16Planes ap = Bf16Planes{{nullptr, nullptr, nullptr}})
+                                                         Bf16Planes ap = Bf16Planes{{nullptr, nullptr, nullptr}},
+                                                         const float *__restrict__ abn = nullptr)
 {
+    static_assert(!(ABN && APRE), "the activation is formed from fp32 rows");
     // chunk depth and LDS row stride in bf16 units.  96-byte rows: ds_read_b128 serves the lane groups {0-3,12-15,20-27}, ... (not
     // 16 consecutive lanes), and fragment reads at (row li, 16-byte piece lq) are conflict-free for strides of 16 B x (2 mod 4);
     // the 80-byte rows used before cost two LDS cycles per group (PMC: more conflict cycles than LDS instruction cycles)
@@ -298,8 +303,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
     }
 
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector type: HIP's uint4 struct kept these arrays in scratch
-    struct Staged { f32x4 a[APRE ? 1 : NAU]; u32x4 ap[APRE ? 3 : 1][NAU]; u32x4 b[3][NBU]; };
+    struct Staged { f32x4 a[APRE ? 1 : NAU]; u32x4 ap[APRE ? 3 : 1][NAU]; u32x4 b[3][NBU]; unsigned ok; };
+    // ABN: scale / shift of this thread's four channels in every chunk position (u % UPR = tid % UPR for all of its units)
+    f32x4 abn_sc[ABN ? CPT : 1], abn_sh[ABN ? CPT : 1];
+    if constexpr (ABN) {
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) {
+            abn_sc[cc] = *reinterpret_cast<const f32x4 *>(abn + cc * KC + 4 * (tid % UPR));
+            abn_sh[cc] = *reinterpret_cast<const f32x4 *>(abn + CR + cc * KC + 4 * (tid % UPR));
+        }
+    }
     auto load_chunk = [&](int chunk, Staged &st) {
+        st.ok = 0u;
         const int ti = chunk / CPT, c0 = (chunk % CPT) * KC;
         const int tap = pm ? (int)((taps >> (4 * ti)) & 15ull) : ti;
         const int kh = tap / g.KW, kw = tap % g.KW;
@@ -316,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
                     st.ap[p][j] = ok ? *reinterpret_cast<const u32x4 *>(ap.p[p] + e + (u % UPR) * 8) : (u32x4){0u, 0u, 0u, 0u};
             } else {
                 st.a[j] = ok ? *reinterpret_cast<const f32x4 *>(src + e + (u % UPR) * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (ABN && ok) st.ok |= 1u << j;
             }
         }
 #pragma unroll
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
             for (int p = 0; p < 3; ++p) st.b[p][j] = *reinterpret_cast<const u32x4 *>(wp.p[p] + e);
         }
     };
-    auto store_chunk = [&](const Staged &st) {
+    auto store_chunk = [&](const Staged &st, int chunk) {
 #pragma unroll
         for (int j = 0; j < NAU; ++j) {
             const int u = tid + 256 * j;
@@ -334,8 +350,20 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
 #pragma unroll
                 for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(&As[p][(u / UPR) * SK + 8 * (u % UPR)]) = st.ap[p][j];
             } else {
+                f32x4 av = st.a[j];
+                if constexpr (ABN) {
+                    const int cc = chunk % CPT;
+                    f32x4 sc = abn_sc[0], sh = abn_sh[0];
+#pragma unroll
+                    for (int q = 1; q < (ABN ? CPT : 1); ++q)
+                        if (cc == q) { sc = abn_sc[q]; sh = abn_sh[q]; }
+                    if (st.ok & (1u << j)) {
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) av[e2] = relu6f(fmaf(av[e2], sc[e2], sh[e2]));
+                    }
+                }
                 bf16x4 h, m, l;
-                split_bf16(st.a[j], h, m, l);
+                split_bf16(av, h, m, l);
                 const int o = (u / UPR) * SK + 4 * (u % UPR);
                 *reinterpret_cast<bf16x4 *>(&As[0][o]) = h;
                 *reinterpret_cast<bf16x4 *>(&As[1][o]) = m;
@@ -379,13 +407,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(const float *__restri
     if (nchunks > 1) load_chunk(1, s1);
     for (int chunk = 0; chunk < nchunks; chunk += 2) {
         __syncthreads();
-        store_chunk(s0);
+        store_chunk(s0, chunk);
         __syncthreads();
         if (chunk + 2 < nchunks) load_chunk(chunk + 2, s0);
         mma_chunk();
         if (chunk + 1 < nchunks) {
             __syncthreads();
-            store_chunk(s1);
+            store_chunk(s1, chunk + 1);
             __syncthreads();
             if (chunk + 3 < nchunks) load_chunk(chunk + 3, s1);
             mma_chunk();
@@ -483,11 +511,14 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char *p)
 // for three products and the wave does 3 x MT x NW MFMA groups per chunk, which moves the kernel from issue-bound on the
 // split arithmetic (one tap: ~250 vector instructions beside 48 MFMAs per wave and chunk) to matrix-bound.
 // DPRE: dz arrives already split (planes `dpl`, NHWC like dzp, which is then unused): its staging is a 16-byte copy per plane.
-template <int CIN, int COUT, int TPB, bool DPRE = false>
+// XBN: `x` is the pre-activation tensor z of the BatchNormalization -> ReLU6 in front of the convolution, xbn = its scale[CIN] | shift[CIN];
+// the activation x = relu6(z * scale + shift) is formed while it is staged (see conv_bf16_kernel<..., ABN>).
+template <int CIN, int COUT, int TPB, bool DPRE = false, bool XBN = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__restrict__ x, const float *__restrict__ dzp,
                                                                   float *__restrict__ dw, const float *__restrict__ zero_page,
                                                                   ConvGeom g, int chunks_per_block, int nranges,
-                                                                  Bf16Planes dpl = Bf16Planes{{nullptr, nullptr, nullptr}})
+                                                                  Bf16Planes dpl = Bf16Planes{{nullptr, nullptr, nullptr}},
+                                                                  const float *__restrict__ xbn = nullptr)
 {
     constexpr int KC = 32;                                        // pixels per chunk
     constexpr int XS = 4 * tr_row_words(CIN), DS = 4 * tr_row_words(COUT);   // row strides in bytes
@@ -530,8 +561,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
     }
     f32x4 sx[TPB][NXU], sd[DPRE ? 1 : NDU];
     u32x4 sdp[DPRE ? 3 : 1][NDU];
+    unsigned xok = 0u;                                            // XBN: which staged x units are real rows (bit j * TPB + t)
+    f32x4 xsc = {0.f, 0.f, 0.f, 0.f}, xsh = {0.f, 0.f, 0.f, 0.f};   // XBN: this thread's four channels (the same for all of its units)
+    if constexpr (XBN) {
+        static_assert(256 % (CIN / 4) == 0 && NXU * TPB <= 32, "one channel group per thread");
+        xsc = *reinterpret_cast<const f32x4 *>(xbn + 4 * (tid % (CIN / 4)));
+        xsh = *reinterpret_cast<const f32x4 *>(xbn + CIN + 4 * (tid % (CIN / 4)));
+    }
     auto load_chunk = [&](int ch) {
         const long m0 = (chunk0 + ch) * KC;
+        xok = 0u;
 #pragma unroll
         for (int j = 0; j < NXU; ++j) {
             const int e = (tid + 256 * j) % (CIN / 4);
@@ -543,6 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
                 const bool ok = xb[j] < g.B && sy >= 0 && sy < g.H && sxx >= 0 && sxx < g.W;
                 const float *p = ok ? x + (((long)xb[j] * g.H + sy) * g.W + sxx) * CIN + 4 * e : zero_page;
                 sx[t][j] = *reinterpret_cast<const f32x4 *>(p);
+                if (XBN && ok) xok |= 1u << (j * TPB + t);
             }
             xpix[j] += KC;
             while (xpix[j] >= HW) { xpix[j] -= HW; ++xb[j]; }
@@ -574,7 +614,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const float *__
         for (int j = 0; j < NXU; ++j) {
             const int u = tid + 256 * j, o = (u / (CIN / 4)) * XS + 8 * (u % (CIN / 4));
 #pragma unroll
-            for (int t = 0; t < TPB; ++t) store_planes(Xs + t * XT, KC * XS, o, sx[t][j]);
+            for (int t = 0; t < TPB; ++t) {
+                f32x4 xv = sx[t][j];
+                if constexpr (XBN) {
+                    if (xok & (1u << (j * TPB + t))) {
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) xv[e2] = relu6f(fmaf(xv[e2], xsc[e2], xsh[e2]));
+                    }
+                }
+                store_planes(Xs + t * XT, KC * XS, o, xv);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NDU; ++j) {

@@ -199,9 +199,9 @@ int launch_wgrad(const float *x, const float *dz, float *dw, const ConvGeom &g, 
 // dW += wgrad(x, dz) in the split-precision form (conv_wgrad_bf16_kernel): grid = (tap groups) * (pixel ranges), one resident
 // round, the taps of a range on one XCD.  TPB = taps per block: 3 (one kernel row, dz split once for three products) pays
 // for conv3 (0.047 -> 0.042 ms); for conv4 its 238 registers and 74 KB of LDS cost more than they save (0.111 -> 0.122 ms).
-template <int CIN, int COUT, int TPB, bool DPRE = false>
+template <int CIN, int COUT, int TPB, bool DPRE = false, bool XBN = false>
 int launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom &g, hipStream_t s, __bf16 *const *dz_planes = nullptr,
-                      bool deterministic = false)
+                      bool deterministic = false, const float *xbn = nullptr)
 {
     if (TPB != 1 && g.KW != TPB) return fail(KWS_ERR_UNSUPPORTED, "split-precision weight gradient expects a kernel %d taps wide", TPB);
     const float *zp = zero_page();
@@ -209,8 +209,8 @@ int launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom
     constexpr size_t stage = (size_t)3 * 32 * 4 * (TPB * tr_row_words(CIN) + tr_row_words(COUT)), tile = (size_t)CIN * COUT * sizeof(float);
     constexpr size_t smem = stage > tile ? stage : tile;
     static const int occ = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        return resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE>, 256, smem);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        return resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>, 256, smem);
     }();
     const long M = (long)g.B * g.Ho * g.Wo, nchunk = (M + 31) / 32;
     const int ngroups = g.KH * g.KW / TPB;
@@ -221,8 +221,8 @@ int launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom
     if (deterministic) { nranges = 8; cpb = (int)nchunk; }   // range 0 takes every chunk: a single add per output element
     static const std::string name = "conv_wgrad_bf16<" + std::to_string(CIN) + "," + std::to_string(COUT) + ">";
     const Bf16Planes dpl{{DPRE ? dz_planes[0] : nullptr, DPRE ? dz_planes[1] : nullptr, DPRE ? dz_planes[2] : nullptr}};
-    KWS_LAUNCH(name.c_str(), (conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE>), dim3((unsigned)(nranges * ngroups)), dim3(256), smem, s, x, dz, dw,
-               zp, g, cpb, (int)nranges, dpl);
+    KWS_LAUNCH(name.c_str(), (conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>), dim3((unsigned)(nranges * ngroups)), dim3(256), smem, s, x, dz, dw,
+               zp, g, cpb, (int)nranges, dpl, xbn);
     return KWS_OK;
 }
 
@@ -287,7 +287,8 @@ static inline int infer_prec(const kws_model *m) { return m->infer_precision >= 
 // returns the number of blocks that wrote BatchNorm partial sums (0: `partial` was not given or the grid exceeds its stride)
 template <int CR, int CO, int MODE, int EPI>
 int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], const float *bias, float *dst, const ConvGeom &g_in,
-                hipStream_t s, double *partial = nullptr, const float *shift = nullptr, __bf16 *const *src_planes = nullptr)
+                hipStream_t s, double *partial = nullptr, const float *shift = nullptr, __bf16 *const *src_planes = nullptr,
+                const float *abn = nullptr)
 {
     ConvGeom g = g_in;
     const long M = MODE == MODE_FWD ? (long)g.B * g.Ho * g.Wo : (long)g.B * g.H * g.W;
@@ -305,6 +306,16 @@ int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], con
     // elsewhere (3 resident blocks per CU overlap their staging and MFMA phases better; measured per kernel at B = 4096)
     constexpr int RT = (MODE == MODE_FWD && CO == 128 && CR == 64) ? 3 : 2;
     const unsigned nblk = blocks_for(M, 32 * RT);
+    if (abn) {
+        // src is the pre-activation tensor of the BatchNormalization -> ReLU6 in front of this layer (conv4's training forward)
+        if constexpr (MODE == MODE_FWD && CR == 64 && CO == 128 && EPI == EPI_RELU) {
+            if (!partial || (int)nblk > kStatStride || src_planes) return fail(KWS_ERR_UNSUPPORTED, "%s: activation-on-load form needs the fused statistics", what);
+            KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, true, false, true>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, partial,
+                       kStatStride, nullptr, (Bf16Planes{{nullptr, nullptr, nullptr}}), abn);
+            return (int)nblk;
+        } else
+            return fail(KWS_ERR_UNSUPPORTED, "%s: no activation-on-load form for this layer", what);
+    }
     if (partial && (int)nblk <= kStatStride && !src_planes) {
         KWS_LAUNCH(name.c_str(), (conv_bf16_kernel<CR, CO, MODE, EPI, RT, true>), dim3(nblk), dim3(256), 0, s, src, wp, bias, dst, g, partial,
                    kStatStride);
@@ -367,6 +378,9 @@ ConvGeom geom3x3(int B, int H, int W, int stride)
 // (l1m_act_pool_moments_kernel<true>) split the conv3 / conv4 / dense weights into their bf16 planes and 16 clear the gradient
 // buffer.  Both jobs used to run on the side stream behind an event and were joined before conv3: two events on the main chain
 // (6-8 us each) for 12 us of work that hides under the activation pass.
+// training in split precision: conv4 and its weight gradient form a3 from z3 on the fly (kws_conv.h: ABN / XBN); the fp32 mode keeps
+// the activation kernel (same-box A/B at B = 4096: 0.6714 -> 0.666 ms per step; KWS_NO_A3_ON_LOAD=1 is the A/B switch)
+static bool cnn_a3_on_load(const kws_model *m, bool bf16, bool training) { return bf16 && training; }
 constexpr int kPrepSplitBlocks = 16, kPrepZeroBlocks = 16, kPrepBlocks = 3 * kPrepSplitBlocks + kPrepZeroBlocks;
 
 // ---- forward ------------------------------------------------------------------------------------------------
@@ -456,6 +470,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                    d.H0, d.W0, cpb);
     }
     bool bound6 = false;
+    static const bool a3_off = getenv("KWS_NO_A3_ON_LOAD") != nullptr;
+    const bool a3_on_load = cnn_a3_on_load(m, bf16, training) && !a3_off;
     for (int l = 1; l < 4; ++l) {
         const float *in = w.a[l - 1];
         const float *kern = params + m->o_k[l];
@@ -503,8 +519,11 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         } else {
             // activation='relu', cnn.py:55
             if (bf16) {
-                fused_stat_blocks = launch_bf16<64, 128, MODE_FWD, EPI_RELU>("conv_bf16_fwd", in, w.wsp[1], nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s,
-                                                                           training ? w.partial : nullptr);
+                // training: a3 = relu6(BN3(z3)) is never written -- conv4 forms it from z3 while it stages its rows, and so does conv4's
+                // weight gradient (conv3 has no pooling, so the activation is a per-element map)
+                fused_stat_blocks = launch_bf16<64, 128, MODE_FWD, EPI_RELU>("conv_bf16_fwd", a3_on_load ? w.z[2] : in, w.wsp[1], nullptr, w.z[3],
+                                                                           geom3x3(B, Hs[3], Ws[3], 1), s, training ? w.partial : nullptr, nullptr, nullptr,
+                                                                           a3_on_load ? coef_of(w.coef[2], 64).scale : nullptr);
                 if (fused_stat_blocks < 0) return fused_stat_blocks;
             } else KWS_TRY(launch_gemm<64, 128, MODE_FWD, EPI_RELU>(in, kern, nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s));
         }
@@ -529,7 +548,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
                                w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
-        } else {
+        } else if (!(l == 2 && a3_on_load)) {
             const long total = M * C;
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
                                w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
@@ -671,7 +690,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
-            if (mprec == 1) KWS_TRY(launch_wgrad_bf16<64, 128, 1, true>(in, nullptr, dk, g, s2, w.dzp, det));
+            static const bool a3_off = getenv("KWS_NO_A3_ON_LOAD") != nullptr;
+            if (mprec == 1 && cnn_a3_on_load(m, true, true) && !a3_off)
+                KWS_TRY((launch_wgrad_bf16<64, 128, 1, true, true>(w.z[2], nullptr, dk, g, s2, w.dzp, det, coef_of(w.coef[2], 64).scale)));
+            else if (mprec == 1) KWS_TRY(launch_wgrad_bf16<64, 128, 1, true>(in, nullptr, dk, g, s2, w.dzp, det));
             else KWS_TRY(launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2, det));
             // grads[o_k[3] ..] (conv4, bn4, dense, head = 82 % of the bytes) are final once the side stream gets here: it
             // runs the dense and conv4 weight gradients in order and joined the caller's stream at fork(3), i.e. after

@@ -93,4 +93,14 @@ __device__ __forceinline__ float wave_sum_dpp(float v)
 }
 #undef KWS_DPP_ADD
 
+// forward-pass arguments of the fused head kernel (kws_layers.h: head_bwd_mfma_kernel<..., FWD = true>)
+struct HeadFwdArgs {
+    const float *b2;
+    const int32_t *labels;
+    const float *class_w;
+    float *probs, *loss_i_out, *correct_i_out;
+    float grad_scale;
+    int ignore_index;
+};
+
 }  // namespace kws

@@ -570,13 +570,20 @@ __global__ __launch_bounds__(256) void head_wgrad_det_kernel(const float *__rest
 //   dW2[k][c] += sum_r x[r][k] dl[r][c]      M = K (K/16 tiles), N = 48 (3 tiles), reduction over the 16 samples (4 k-steps)
 //   dx[r][k]   = sum_c dl[r][c] W2[k][c]      M = 16 samples, N = K (K/16 tiles), reduction over 48 padded classes (12 k-steps)
 // dl and W2 are zero-padded to 48 columns in LDS, so no lane needs a mask; dW2 / db2 are added with float atomics as before.
-template <bool RELU6_GATE, int GROUPS>
+// FWD (train step, GROUPS == 1): the kernel is the head's FORWARD as well -- logits from the staged tile and W2 (the k-ascending fmaf
+// chain of head_fwd_fast_kernel), first-maximum arg-max, softmax, the per-sample loss of loss.py and dlogits, which go straight into
+// the LDS tile the two products read.  One launch and the (B, C) dlogits round trip less on the step's critical chain (11 us of
+// head_fwd + launch gap at B = 4096).  The per-sample losses / correct flags go to loss_i_out / correct_i_out and are summed by
+// loss_reduce_kernel (on the side stream), `dlogits`, `loss_i`, `correct_i` and `stats` are then unused.
+template <bool RELU6_GATE, int GROUPS, bool FWD = false>
 __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w2,
                                                              const float *__restrict__ dlogits, float *__restrict__ dx,
                                                              float *__restrict__ dw2, float *__restrict__ db2, int B, int K, int C,
                                                              float *__restrict__ dx_colsum, const float *__restrict__ loss_i,
-                                                             const float *__restrict__ correct_i, float *__restrict__ stats)
+                                                             const float *__restrict__ correct_i, float *__restrict__ stats,
+                                                             HeadFwdArgs fw = HeadFwdArgs{})
 {
+    static_assert(!FWD || GROUPS == 1, "the fused forward handles one 16-sample group per block");
     // dx_colsum (nullable): += column sums of dx, i.e. the bias gradient of the layer that produced x (float atomics).
     // stats (nullable): block 0 also writes {sum of loss_i, sum of correct_i} in a fixed order (double), which saves the
     // separate loss_reduce launch of a train step.
@@ -601,7 +608,58 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restr
         if (b0 >= B) break;
         __syncthreads();                            // the previous group's reads of xs / ds are done
         for (int i = threadIdx.x; i < 16 * K; i += 256) { const int r = i / K, k = i - r * K; xs[r * KS + k] = (b0 + r < B) ? x[(long)(b0 + r) * K + k] : 0.f; }
-        for (int i = threadIdx.x; i < 16 * CP; i += 256) { const int r = i / CP, c = i - r * CP; ds[r * CS + c] = (c < C && b0 + r < B) ? dlogits[(long)(b0 + r) * C + c] : 0.f; }
+        if constexpr (!FWD) {
+            for (int i = threadIdx.x; i < 16 * CP; i += 256) { const int r = i / CP, c = i - r * CP; ds[r * CS + c] = (c < C && b0 + r < B) ? dlogits[(long)(b0 + r) * C + c] : 0.f; }
+        } else {
+            __syncthreads();                        // ws (staged above) and xs are complete
+            // ---- forward: thread (sample sm = tid / 16, lane j = tid % 16) owns classes j, j + 16, j + 32 of its sample ----
+            const int sm = threadIdx.x >> 4, j = threadIdx.x & 15, b = b0 + sm;
+            float *lg = ds + sm * CS;               // the sample's row of the dlogits tile doubles as its logits
+            for (int c = j; c < CP; c += 16) {
+                float acc = 0.f;
+                if (c < C) {
+                    for (int k = 0; k < K; ++k) acc = fmaf(xs[sm * KS + k], ws[k * CS + c], acc);
+                    acc += fw.b2[c];
+                }
+                lg[c] = acc;
+            }
+            // the 16 lanes of a sample sit in one wave: LDS operations of a wave are in order, no barrier needed between these steps
+            float mx = -INFINITY;
+            int am = 0x7fffffff;
+            for (int c = j; c < C; c += 16) {
+                const float v = lg[c];
+                if (v > mx) { mx = v; am = c; }
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const float omx = __shfl_xor(mx, o, 16);
+                const int oam = __shfl_xor(am, o, 16);
+                if (omx > mx || (omx == mx && oam < am)) { mx = omx; am = oam; }
+            }
+            float sum = 0.f;
+            for (int c = j; c < C; c += 16) { const float e = expf(lg[c] - mx); lg[c] = e; sum += e; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
+            const float rs = 1.f / sum;
+            const bool live = b < B;
+            const int y = live ? fw.labels[b] : 0;
+            const float py = lg[y] * rs;
+            float loss, coef;
+            if (fw.class_w) {                       // loss.py:67-71: -log(p_y) * w_y, no clipping
+                loss = -logf(py) * fw.class_w[y];
+                coef = fw.class_w[y];
+            } else {                                // loss.py:36: K.categorical_crossentropy on probabilities (clipped)
+                const float lo = kCeEps, hi = 1.f - kCeEps;
+                loss = -logf(fminf(fmaxf(py, lo), hi));
+                coef = (py >= lo && py <= hi) ? 1.f : 0.f;
+            }
+            if (fw.ignore_index > 0 && y == fw.ignore_index) { loss = 0.f; coef = 0.f; }   // loss.py:38-40,73-75
+            if (live && j == 0) { fw.loss_i_out[b] = loss; fw.correct_i_out[b] = am == y ? 1.f : 0.f; }
+            if (live && fw.probs)
+                for (int c = j; c < C; c += 16) fw.probs[(long)b * C + c] = lg[c] * rs;
+            for (int c = j; c < CP; c += 16)
+                lg[c] = (live && c < C) ? (lg[c] * rs - (c == y ? 1.f : 0.f)) * coef * fw.grad_scale : 0.f;
+        }
         __syncthreads();
         // dx tiles: one per 16 input features, dealt to the waves
         for (int nt = wave; nt < KT; nt += 4) {

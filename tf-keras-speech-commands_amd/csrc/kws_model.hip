@@ -569,8 +569,10 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
 // ---- backward -----------------------------------------------------------------------------------------------
 int cnn_backward(const kws_model *m, const float *feat, int B, const float *params, float *grads, CnnWs &w, uint64_t seed,
                  hipEvent_t bucket_event, hipStream_t s, float *stats, bool grads_zeroed = false, const double *moments = nullptr,
-                 OverlapHook *hook = nullptr, kws_comm *comm = nullptr)
+                 OverlapHook *hook = nullptr, kws_comm *comm = nullptr, const kws_train_args *fused_head = nullptr)
 {
+    // fused_head != nullptr: the head's forward pass (logits, softmax, loss, dlogits) has NOT run; the head's backward kernel does it
+    // (cnn_head_fwd_fused below decides)
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
     const int Hz[4] = {d.H0, d.H1, d.H3, d.H3}, Wz[4] = {d.W0, d.W1, d.W3, d.W3};
@@ -606,9 +608,19 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         // (deterministic mode launches two kernels here and keeps the recorded events)
         fork0_ev = (hook && hook->wants(2) && hook->ev) ? hook->ev : R->ev[0];
         if (!det && !no_arm) arm_stop_event(fork0_ev, s);
-        KWS_TRY(run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s, fuse && !det ? grads + m->o_db : nullptr, w.loss_i, w.correct_i,
-                             fuse ? stats : nullptr, det));
+        if (fused_head) {
+            const kws_train_args *a = fused_head;
+            const HeadFwdArgs hf{params + m->o_hb, a->labels, a->class_weights, a->probs, w.loss_i, w.correct_i, a->grad_scale / (float)B, a->ignore_index};
+            KWS_TRY(run_head_bwd(m, B, params, w.d1, nullptr, w.dd1, grads, true, s, grads + m->o_db, nullptr, nullptr, nullptr, false, &hf));
+        } else
+            KWS_TRY(run_head_bwd(m, B, params, w.d1, w.dlogits, w.dd1, grads, true, s, fuse && !det ? grads + m->o_db : nullptr, w.loss_i, w.correct_i,
+                                 fuse ? stats : nullptr, det));
         fork0_bound = stop_event_bound(fork0_ev);
+        if (fused_head) {
+            // the forward pass and the loss are enqueued only now
+            if (fused_head->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(fused_head->forward_event), s));
+            if (hook) KWS_TRY(hook->fire(1, s));
+        }
     }
     // dense 256->128: bias grad (column sums), wgrad, dgrad -> da4 (gradient w.r.t. the dropped, flattened map)
     {
@@ -623,6 +635,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (!fork0_bound) KWS_HIP_CHECK(hipEventRecord(R->ev[0], s));
             KWS_HIP_CHECK(hipStreamWaitEvent(s2, R->ev[0], 0));
         }
+        // fused head: the sums of the per-sample losses / correct flags, in a fixed order, off the main chain
+        if (fused_head && stats) KWS_LAUNCH("loss_reduce_kernel", loss_reduce_kernel, dim3(1), dim3(256), 0, s2, w.loss_i, w.correct_i, B, stats);
         KWS_TRY(launch_wgrad<128, 128, 1>(w.a[3], w.dd1, grads + m->o_dk, g, s2, det));
         int nblk, rows;
         stat_grid(B, 128, nblk, rows);
@@ -1035,7 +1049,7 @@ bool head_bwd_fuses(const kws_model *m) { return m->head_K % 16 == 0 && m->head_
 
 int run_head_bwd(const kws_model *m, int B, const float *params, const float *x, const float *dlogits, float *dx,
                  float *grads, bool relu6_gate, hipStream_t s, float *dx_colsum, const float *loss_i, const float *correct_i,
-                 float *stats, bool deterministic)
+                 float *stats, bool deterministic, const HeadFwdArgs *fwd)
 {
     const int K = m->head_K;
     // deterministic: the kernels below only produce dx (and the loss sums); dW2 / db2 come from a batch-ordered kernel
@@ -1049,6 +1063,13 @@ int run_head_bwd(const kws_model *m, int B, const float *params, const float *x,
     if (head_bwd_fuses(m)) {    // the MFMA form: W2, a 16-sample tile and dlogits padded to 48 classes live in LDS
         constexpr int G = 1;                          // 16-sample groups per block (4 measured slower: 64 blocks expose each group's staging latency)
         const size_t smem_fast = sizeof(float) * (size_t)(16 * (K + 2) + (16 + K) * 50);
+        if (fwd) {          // the train step's fused form: forward + loss + both backward products (kws_layers.h)
+            if (!relu6_gate || deterministic) return fail(KWS_ERR_INVALID, "the fused head kernel serves the non-deterministic train step of simple_cnn");
+            KWS_LAUNCH("head_fwd_bwd_kernel", (head_bwd_mfma_kernel<true, 1, true>), dim3(blocks_for(B, 16)), dim3(256), smem_fast, s, x, params + m->o_hk,
+                       nullptr, dx, dw2, db2, B, K, m->C, dx_colsum, nullptr, nullptr, nullptr, *fwd);
+            KWS_LAUNCH_CHECK("head forward + backward");
+            return KWS_OK;
+        }
         if (relu6_gate)
             KWS_LAUNCH("head_bwd_kernel", (head_bwd_mfma_kernel<true, G>), dim3(blocks_for(B, 16 * G)), dim3(256), smem_fast, s, x, params + m->o_hk, dlogits,
                        dx, dw2, db2, B, K, m->C, dx_colsum, loss_i, correct_i, stats);
@@ -1352,14 +1373,20 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     // Keras reduces the per-sample losses with a batch mean (train.py:75-77): d(mean)/d(logits) carries 1/B
     // simple_cnn: the head's backward kernel also sums the per-sample losses (no separate loss_reduce launch)
     const bool fuse_stats = !lite && head_bwd_fuses(m);
-    rc = run_head(m, a->B, a->params, w.d1, w.loss_i, w.correct_i, a->labels, a->class_weights, a->probs, nullptr, w.dlogits,
-                  a->grad_scale / (float)a->B, fuse_stats ? nullptr : a->stats, a->ignore_index, s);
-    if (rc) return rc;
-    if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
-    if (!lite) KWS_TRY(hook.fire(1, s));
+    // simple_cnn (non-deterministic mode): the head's forward pass rides in its backward kernel (kws_layers.h: head_bwd_mfma_kernel<.., FWD>):
+    // one launch and the dlogits round trip less on the main chain (same-box: -11 us upper bound measured by skipping the launch)
+    static const bool head_fuse_off = getenv("KWS_NO_HEAD_FUSION") != nullptr;
+    const bool fuse_head_fwd = fuse_stats && !m->deterministic && !head_fuse_off;
+    if (!fuse_head_fwd) {
+        rc = run_head(m, a->B, a->params, w.d1, w.loss_i, w.correct_i, a->labels, a->class_weights, a->probs, nullptr, w.dlogits,
+                      a->grad_scale / (float)a->B, fuse_stats ? nullptr : a->stats, a->ignore_index, s);
+        if (rc) return rc;
+        if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
+        if (!lite) KWS_TRY(hook.fire(1, s));
+    }
     rc = lite ? lite_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s)
               : cnn_backward(m, a->feat, a->B, a->params, a->grads, w, a->dropout_seed, static_cast<hipEvent_t>(a->bucket_event), s,
-                             fuse_stats ? a->stats : nullptr, grads_zeroed, a->feat_moments, &hook, a->comm);
+                             fuse_stats ? a->stats : nullptr, grads_zeroed, a->feat_moments, &hook, a->comm, fuse_head_fwd ? a : nullptr);
     if (rc || !a->comm) return rc;
     // simple_cnn reduced its early bucket on the side stream (joined again by now); the rest, and the BatchNormalization moving
     // statistics, go behind the backward pass on the caller's stream.  simple_cnn_lite has no side stream: both buckets here.

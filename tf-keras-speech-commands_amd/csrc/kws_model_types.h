@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "kws_common.h"
+#include "kws_device.h"
 
 namespace kws {
 
@@ -97,7 +98,7 @@ int run_head(const kws_model *m, int B, const float *params, const float *x, flo
 bool head_bwd_fuses(const kws_model *m);
 int run_head_bwd(const kws_model *m, int B, const float *params, const float *x, const float *dlogits, float *dx,
                  float *grads, bool relu6_gate, hipStream_t s, float *dx_colsum = nullptr, const float *loss_i = nullptr,
-                 const float *correct_i = nullptr, float *stats = nullptr, bool deterministic = false);
+                 const float *correct_i = nullptr, float *stats = nullptr, bool deterministic = false, const HeadFwdArgs *fwd = nullptr);
 
 // simple_gru (kws_rnn.hip)
 size_t gru_workspace_bytes(const kws_model *m, int B, bool training);

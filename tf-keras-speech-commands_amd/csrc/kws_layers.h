@@ -139,11 +139,14 @@ __global__ void bn_infer_coef_all_kernel(BnInferAll a)
 }
 
 // y = relu6(z*scale + shift), optional 2x2/2 'valid' max-pool, optional inverted dropout on the result
+// zmax_out / arg_out (POOL, training): the pre-BatchNorm value z of the window's routed element (the FIRST maximum of relu6(y), the rule
+// of the backward pass) and its index 0..3 -- what bn_bwd_reduce_routed_kernel needs instead of a second pass over the 4x larger z.
 template <bool POOL>
 __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float *__restrict__ z, const float *__restrict__ scale,
                                                            const float *__restrict__ shift, float *__restrict__ a, int B,
                                                            int H, int W, int C, float drop_rate, uint32_t seed_lo,
-                                                           uint32_t seed_hi)
+                                                           uint32_t seed_hi, float *__restrict__ zmax_out = nullptr,
+                                                           unsigned char *__restrict__ arg_out = nullptr)
 {
     const int Hp = POOL ? H / 2 : H, Wp = POOL ? W / 2 : W;
     const long total = (long)B * Hp * Wp * C, idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -157,8 +160,19 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float *__restric
     float v;
     if (POOL) {
         const float *p = z + (((long)b * H + 2 * ph) * W + 2 * pw) * C + c;
-        v = fmaxf(fmaxf(fmaf(p[0], sc, sh), fmaf(p[C], sc, sh)),
-                  fmaxf(fmaf(p[(long)W * C], sc, sh), fmaf(p[(long)W * C + C], sc, sh)));
+        const float z0 = p[0], z1 = p[C], z2 = p[(long)W * C], z3 = p[(long)W * C + C];
+        const float y0 = fmaf(z0, sc, sh), y1 = fmaf(z1, sc, sh), y2 = fmaf(z2, sc, sh), y3 = fmaf(z3, sc, sh);
+        v = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+        if (zmax_out) {                  // first maximum of relu6(y): the element the backward pass routes the gradient to
+            int arg = 0;
+            float best = relu6f(y0), zm = z0;
+            const float v1 = relu6f(y1), v2 = relu6f(y2), v3 = relu6f(y3);
+            if (v1 > best) { best = v1; arg = 1; zm = z1; }
+            if (v2 > best) { best = v2; arg = 2; zm = z2; }
+            if (v3 > best) { arg = 3; zm = z3; }
+            zmax_out[idx] = zm;
+            arg_out[idx] = (unsigned char)arg;
+        }
     } else {
         v = fmaf(z[idx], sc, sh);
     }
@@ -290,6 +304,48 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const float *__
             if (e < nbh * W) { ih = 2 * Hp + e / W; iw = e % W; }
             else { const int e2 = e - nbh * W; ih = e2 / nbw; iw = 2 * Wp + e2 % nbw; }
             gz[(((long)b * H + ih) * W + iw) * C + c] = 0.f;
+        }
+    }
+    __shared__ double shm[2][256];
+    shm[0][threadIdx.x] = s;
+    shm[1][threadIdx.x] = sx;
+    __syncthreads();
+    if (r == 0) {
+        for (int j = 1; j < R; ++j) { s += shm[0][j * C + c]; sx += shm[1][j * C + c]; }
+        partial[((long)0 * C + c) * kStatStride + blockIdx.x] = s;
+        partial[((long)1 * C + c) * kStatStride + blockIdx.x] = sx;
+    }
+}
+
+// The pooled backward reduction from what the forward pass left per (pool window, channel): zmax (z of the routed element) and arg (its
+// index, consumed by the data / weight gradient kernels).  Same arithmetic as bn_bwd_reduce_pool_kernel<true> on that element -- the gate
+// on y = z scale + shift, g, sum g, sum g xhat -- without reading the four z values of every window again (conv2: 38 instead of 114 MB).
+// da is overwritten with the routed, gated gradient (the compact form).  One thread per (window, channel), grid-stride over windows.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_routed_kernel(const float *__restrict__ zmax, float *da, BnCoef k, long NW, int C,
+                                                                    int wins_per_block, double *__restrict__ partial)
+{
+    const int c = threadIdx.x % C, r = threadIdx.x / C, R = 256 / C;
+    const long beg = (long)blockIdx.x * wins_per_block;
+    const long end = beg + wins_per_block < NW ? beg + wins_per_block : NW;
+    const float sc = k.scale[c], sh = k.shift[c], mean = k.mean[c], inv = k.inv[c];
+    double s = 0.0, sx = 0.0;
+    for (long q0 = beg + r; q0 < end; q0 += 4 * R) {       // four windows per trip: their loads are issued together
+        float za[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long q = q0 + (long)u * R, qc = q < end ? q : end - 1;
+            za[u] = zmax[qc * C + c];
+            g[u] = da[qc * C + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long q = q0 + (long)u * R;
+            if (q >= end) continue;
+            const float ya = fmaf(za[u], sc, sh);
+            const float gv = (ya > 0.f && ya < 6.f) ? g[u] : 0.f;
+            da[q * C + c] = gv;
+            s += (double)gv;
+            sx += (double)gv * (double)((za[u] - mean) * inv);
         }
     }
     __shared__ double shm[2][256];

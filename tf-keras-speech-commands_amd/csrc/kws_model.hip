@@ -70,6 +70,8 @@ struct CnnWs {
     __bf16 *dzp[3];     // simple_cnn training: h/m/l planes of dz4 (written by BN4's backward, read by conv4's data / weight gradients)
     double *partial;    // [kMaxStatBlocks][2][256]
     double *moments;    // Q[10][10] of the feature map (kws_layer1_moments.h) when the caller did not supply it
+    float *zmax2;       // training: z2 at the routed element of every pool window of layer 2, and
+    unsigned char *arg2;   // that element's index (written by the forward activation kernel, kws_layers.h: bn_bwd_reduce_routed_kernel)
     unsigned char *base;
     size_t bytes;
 };
@@ -110,6 +112,8 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
         for (int p = 0; p < 3; ++p) w.dzp[p] = reinterpret_cast<__bf16 *>(take(lite ? 0 : (zs[3] * B + 1) / 2));
         for (int i = 0; i < 4; ++i) w.ddw[i] = take(lite ? dws[i] * B : 0);
         for (int i = 0; i < 3; ++i) w.da[i] = take(as[i] * B);
+        w.zmax2 = take(lite ? 0 : as[1] * B);
+        w.arg2 = reinterpret_cast<unsigned char *>(take(lite ? 0 : (as[1] * B + 3) / 4));
     }
     w.bytes = off;
     return w;
@@ -378,6 +382,13 @@ ConvGeom geom3x3(int B, int H, int W, int stride)
 // (l1m_act_pool_moments_kernel<true>) split the conv3 / conv4 / dense weights into their bf16 planes and 16 clear the gradient
 // buffer.  Both jobs used to run on the side stream behind an event and were joined before conv3: two events on the main chain
 // (6-8 us each) for 12 us of work that hides under the activation pass.
+// conv2's backward pass in split precision keeps g compact (the routed value per pool window + the element index), when the clip
+// fits the kernels' staging; the forward activation kernel of layer 2 then also leaves zmax / arg for the routed backward reduction
+static bool cnn_compact_g2(const kws_model *m, bool bf16)
+{
+    const CnnDims &d = m->d;
+    return bf16 && d.H1 * d.W1 * 8 <= 1280 && (size_t)(d.H1 / 2) * (d.W1 / 2) * 32 <= sizeof(float) * (size_t)d.H3 * d.W3 * 64;
+}
 // training in split precision: conv4 and its weight gradient form a3 from z3 on the fly (kws_conv.h: ABN / XBN); the fp32 mode keeps
 // the activation kernel (same-box A/B at B = 4096: 0.6714 -> 0.666 ms per step; KWS_NO_A3_ON_LOAD=1 is the A/B switch)
 static bool cnn_a3_on_load(const kws_model *m, bool bf16, bool training) { return bf16 && training; }
@@ -472,6 +483,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     bool bound6 = false;
     static const bool a3_off = getenv("KWS_NO_A3_ON_LOAD") != nullptr;
     const bool a3_on_load = cnn_a3_on_load(m, bf16, training) && !a3_off;
+    static const bool routed_off = getenv("KWS_NO_ROUTED_BWD") != nullptr;
+    const bool routed_bwd2 = cnn_compact_g2(m, bf16) && !routed_off;
     for (int l = 1; l < 4; ++l) {
         const float *in = w.a[l - 1];
         const float *kern = params + m->o_k[l];
@@ -546,8 +559,9 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         if (arm6) arm_stop_event(hook->ev, s);
         if (pool[l]) {
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
+            const bool routed = l == 1 && training && routed_bwd2;
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
-                               w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi);
+                               w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi, routed ? w.zmax2 : nullptr, routed ? w.arg2 : nullptr);
         } else if (!(l == 2 && a3_on_load)) {
             const long total = M * C;
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
@@ -649,6 +663,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         if (hook) KWS_TRY(hook->fire(3, s));
     }
     int fused_bn3_blocks = 0;          // > 0: conv4's data gradient already did layer 3's BatchNorm-backward reduction
+    static const bool routed_off = getenv("KWS_NO_ROUTED_BWD") != nullptr;
+    const bool routed_bwd2 = cnn_compact_g2(m, mprec == 1) && !routed_off;      // the forward pass left zmax2 / arg2 (same predicate)
     for (int l = 3; l >= 1; --l) {
         if (hook && l == 2) KWS_TRY(hook->fire(5, s));
         const int C = kCh[l + 1];
@@ -662,12 +678,14 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         // conv2 (split precision): g stays compact -- the routed value per pool window in place of da[1], the element index as
         // a byte in the (dead by now) da[2] buffer -- and the clip data gradient rebuilds it while staging: 54 MB less to
         // write here and 54 MB less to read there at B = 4096
-        const bool compact_g = l == 1 && mprec == 1 && Hz[1] * Wz[1] * 8 <= 1280 &&
-                               (size_t)(Hz[1] / 2) * (Wz[1] / 2) * 32 <= sizeof(float) * (size_t)d.H3 * d.W3 * 64;
+        const bool compact_g = l == 1 && cnn_compact_g2(m, mprec == 1);
         if (pool[l]) {
             const long NW = (long)B * (Hz[l] / 2) * (Wz[l] / 2);       // one thread per (pool window, channel)
             stat_grid(NW, C, nblk, rows);
-            if (compact_g)
+            if (compact_g && routed_bwd2)
+                KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_routed_kernel, dim3(nblk), dim3(256), 0, s, w.zmax2, w.da[1], k, NW, C,
+                           rows, w.partial);
+            else if (compact_g)
                 KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_pool_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], w.da[1], k,
                            w.gz[l], B, Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi, reinterpret_cast<unsigned char *>(w.da[2]));
             else
@@ -741,7 +759,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             // dgrad forms dz2 from (g, z2) while staging and leaves it in gz[1]; wgrad then overlaps with layer 1's kernels
             const size_t smd = sizeof(float) * (size_t)(H1 + 2) * (W1 + 2) * (32 + 4);
             BnBwdArgs bn = {w.z[1], params + m->o_g[1], k.mean, k.inv, k.k2, k.k3};
-            if (compact_g) { bn.gw = w.da[1]; bn.arg = reinterpret_cast<const unsigned char *>(w.da[2]); }
+            if (compact_g) { bn.gw = w.da[1]; bn.arg = routed_bwd2 ? w.arg2 : reinterpret_cast<const unsigned char *>(w.da[2]); }
             const bool wgrad_bf16 = mprec == 1 && H1 * W1 <= 160;
             // compact g and a clip that fits the kernels' register staging: the weight gradient forms dz itself (from the routed g
             // and z2), so it forks BEFORE the data gradient and runs beside it and beside layer 1 on the side stream; the data

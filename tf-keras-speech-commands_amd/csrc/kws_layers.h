@@ -359,6 +359,57 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_routed_kernel(const float *
     }
 }
 
+// The same for a consumer that wants the full-size g (layer 4: bn_bwd_apply_planes reads gz): zmax / arg from the forward pass replace
+// the four z loads of every window; dropout, gate, sums and the zero fill of the pixels outside every window as in
+// bn_bwd_reduce_pool_kernel<false>.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_routed_full_kernel(const float *__restrict__ zmax, const unsigned char *__restrict__ argin,
+                                                                         const float *__restrict__ da, BnCoef k, float *__restrict__ gz, int B,
+                                                                         int H, int W, int C, int wins_per_block, double *__restrict__ partial,
+                                                                         float drop_rate, uint32_t seed_lo, uint32_t seed_hi)
+{
+    const int c = threadIdx.x % C, r = threadIdx.x / C, R = 256 / C;
+    const int Hp = H / 2, Wp = W / 2;
+    const long NW = (long)B * Hp * Wp, beg = (long)blockIdx.x * wins_per_block;
+    const long end = beg + wins_per_block < NW ? beg + wins_per_block : NW;
+    const float sc = k.scale[c], sh = k.shift[c], mean = k.mean[c], inv = k.inv[c];
+    double s = 0.0, sx = 0.0;
+    for (long q = beg + r; q < end; q += R) {
+        const int win = (int)(q % ((long)Hp * Wp)), b = (int)(q / ((long)Hp * Wp)), ph = win / Wp, pw = win % Wp;
+        const long o00 = (((long)b * H + 2 * ph) * W + 2 * pw) * C + c;
+        const long off[4] = {o00, o00 + C, o00 + (long)W * C, o00 + (long)W * C + C};
+        const float za = zmax[q * C + c];
+        const int arg = argin[q * C + c];
+        float g = da[q * C + c];
+        if (drop_rate > 0.f) g = dropout_keep(seed_lo, seed_hi, (uint32_t)(q * C + c), drop_rate) ? g / (1.f - drop_rate) : 0.f;
+        const float ya = fmaf(za, sc, sh);
+        g = (ya > 0.f && ya < 6.f) ? g : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gz[off[j]] = j == arg ? g : 0.f;
+        s += (double)g;
+        sx += (double)g * (double)((za - mean) * inv);
+    }
+    const int nbh = H - 2 * Hp, nbw = W - 2 * Wp;          // pixels outside every window: g = 0 (only when H or W is odd)
+    if (nbh || nbw) {
+        const long per = (long)nbh * W + (long)nbw * 2 * Hp, NB = (long)B * per;
+        for (long q = (long)blockIdx.x * (256 / C) + r; q < NB; q += (long)gridDim.x * (256 / C)) {
+            const int b = (int)(q / per), e = (int)(q % per);
+            int ih, iw;
+            if (e < nbh * W) { ih = 2 * Hp + e / W; iw = e % W; }
+            else { const int e2 = e - nbh * W; ih = e2 / nbw; iw = 2 * Wp + e2 % nbw; }
+            gz[(((long)b * H + ih) * W + iw) * C + c] = 0.f;
+        }
+    }
+    __shared__ double shm[2][256];
+    shm[0][threadIdx.x] = s;
+    shm[1][threadIdx.x] = sx;
+    __syncthreads();
+    if (r == 0) {
+        for (int j = 1; j < R; ++j) { s += shm[0][j * C + c]; sx += shm[1][j * C + c]; }
+        partial[((long)0 * C + c) * kStatStride + blockIdx.x] = s;
+        partial[((long)1 * C + c) * kStatStride + blockIdx.x] = sx;
+    }
+}
+
 __global__ void bn_bwd_finalize_kernel(const double *__restrict__ partial, int nblk, long M, int C,
                                        const float *__restrict__ gamma, float *__restrict__ dgamma,
                                        float *__restrict__ dbeta, BnCoef k)

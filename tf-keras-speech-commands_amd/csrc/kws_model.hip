@@ -72,6 +72,8 @@ struct CnnWs {
     double *moments;    // Q[10][10] of the feature map (kws_layer1_moments.h) when the caller did not supply it
     float *zmax2;       // training: z2 at the routed element of every pool window of layer 2, and
     unsigned char *arg2;   // that element's index (written by the forward activation kernel, kws_layers.h: bn_bwd_reduce_routed_kernel)
+    float *zmax4;       // the same for layer 4 (full-size g: bn_bwd_reduce_routed_full_kernel)
+    unsigned char *arg4;
     unsigned char *base;
     size_t bytes;
 };
@@ -114,6 +116,8 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
         for (int i = 0; i < 3; ++i) w.da[i] = take(as[i] * B);
         w.zmax2 = take(lite ? 0 : as[1] * B);
         w.arg2 = reinterpret_cast<unsigned char *>(take(lite ? 0 : (as[1] * B + 3) / 4));
+        w.zmax4 = take(lite ? 0 : as[3] * B);
+        w.arg4 = reinterpret_cast<unsigned char *>(take(lite ? 0 : (as[3] * B + 3) / 4));
     }
     w.bytes = off;
     return w;
@@ -559,9 +563,13 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         if (arm6) arm_stop_event(hook->ev, s);
         if (pool[l]) {
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
-            const bool routed = l == 1 && training && routed_bwd2;
+            // training: the routed element of every window for the backward reduction (layer 2: compact g; layer 4: full-size g)
+            float *zm = nullptr;
+            unsigned char *ag = nullptr;
+            if (l == 1 && training && routed_bwd2) { zm = w.zmax2; ag = w.arg2; }
+            if (l == 3 && training && bf16 && !routed_off) { zm = w.zmax4; ag = w.arg4; }
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
-                               w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi, routed ? w.zmax2 : nullptr, routed ? w.arg2 : nullptr);
+                               w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi, zm, ag);
         } else if (!(l == 2 && a3_on_load)) {
             const long total = M * C;
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
@@ -688,6 +696,9 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             else if (compact_g)
                 KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_pool_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], w.da[1], k,
                            w.gz[l], B, Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi, reinterpret_cast<unsigned char *>(w.da[2]));
+            else if (l == 3 && mprec == 1 && !routed_off)
+                KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_routed_full_kernel, dim3(nblk), dim3(256), 0, s, w.zmax4, w.arg4, da, k,
+                           w.gz[l], B, Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);
             else
                 KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_pool_kernel<false>, dim3(nblk), dim3(256), 0, s, w.z[l],
                            const_cast<float *>(da), k, w.gz[l], B, Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);

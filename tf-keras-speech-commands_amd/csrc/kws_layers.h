@@ -722,14 +722,17 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restr
             // ---- forward: thread (sample sm = tid / 16, lane j = tid % 16) owns classes j, j + 16, j + 32 of its sample ----
             const int sm = threadIdx.x >> 4, j = threadIdx.x & 15, b = b0 + sm;
             float *lg = ds + sm * CS;               // the sample's row of the dlogits tile doubles as its logits
-            for (int c = j; c < CP; c += 16) {
-                float acc = 0.f;
-                if (c < C) {
-                    for (int k = 0; k < K; ++k) acc = fmaf(xs[sm * KS + k], ws[k * CS + c], acc);
-                    acc += fw.b2[c];
-                }
-                lg[c] = acc;
+            // logits[16 samples][48] = xs[16][K] . ws[K][48] on the fp32 MFMA (a k-ascending fmaf chain per element, as the vector form):
+            // wave nt owns the 16-class tile nt; the padded columns of ws are zero
+            if (wave < CP / 16) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int kk = 0; kk < K / 4; ++kk) acc = mfma16(xs[li * KS + 4 * kk + lq], ws[(4 * kk + lq) * CS + 16 * wave + li], acc);
+                const int cc = 16 * wave + li;
+                const float bv = cc < C ? fw.b2[cc] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ds[(4 * lq + r) * CS + cc] = acc[r] + bv;
             }
+            __syncthreads();
             // the 16 lanes of a sample sit in one wave: LDS operations of a wave are in order, no barrier needed between these steps
             float mx = -INFINITY;
             int am = 0x7fffffff;

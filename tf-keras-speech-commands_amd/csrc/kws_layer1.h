@@ -352,18 +352,29 @@ __device__ __forceinline__ void l1m_route(const f32x4 &z, float sc, float sh, fl
 
 // Forward body (conv1 -> BN -> ReLU6 -> 2x2 max) for a compile-time map size, shared by the training and the inference kernel.  The
 // generic loop below visits the windows four at a time in index order and pays a coordinate walk with wrap loops per tile; a1 does
-// not care in which order it is written, so quadrant q of every tile walks its own contiguous run of windows (window = q * NT + t):
-// a lane's window advances by one per tile -- +2 floats or the row jump, one compare and two selects -- and the z product of tile
-// t+1 is issued before tile t is finished (kws_layer1_fast.h has the backward pass in the same form).
+// not care in which order it is written, so quadrant q of every tile walks its own run of whole window ROWS: RR = ceil(Hp / 4) rows
+// = RL = RR * Wp windows (30 x 20 map: 4 rows, 40 windows; quadrant 3 has only 3 real rows).  Window t of a run then sits at the
+// compile-time offset (t / Wp) * 2 WP + (t % Wp) * 2 from the run's origin: inside a group of Wp tiles the LDS reads use immediate
+// offsets and no lane computes an address (kws_layer1_fast.h has the backward pass in the same form).
+template <int H, int W>
+struct L1Runs {
+    static constexpr int WP = W + 2, Wp = W / 2, Hp = H / 2, NWIN = Hp * Wp, NXS = (H + 2) * WP, HW = H * W;
+    static constexpr int RR = (Hp + 3) / 4, RL = RR * Wp;            // window rows / windows per quadrant run
+    static constexpr int NST = (NXS + 63) / 64;
+    // LDS floats per wave: the haloed map plus the rows a run past the map's end (quadrant 3) still reads
+    static constexpr int TILE = ((H + 2 + 2 * (4 * RR - Hp)) * WP + 3) & ~3;
+    static_assert(H % 2 == 0 && W % 2 == 0 && NST <= kL1Stage && 4 * RL >= NWIN && 3 * RL < NWIN, "map size");
+};
+
 template <int H, int W>
 __device__ __forceinline__ void l1f_forward_clips(const float *__restrict__ feat, const float *__restrict__ wk, float sc, float sh,
                                                   float *__restrict__ a1, int B, int clips_per_wave, float *smem)
 {
-    constexpr int WP = W + 2, Wp = W / 2, Hp = H / 2, NWIN = Hp * Wp, NT = (NWIN + 3) / 4, NXS = (H + 2) * WP, HW = H * W;
-    constexpr int NST = (NXS + 63) / 64, LAST = NWIN - 3 * NT, kWrap = 2 * WP - 2 * (Wp - 1), UN = 6;
-    static_assert(H % 2 == 0 && W % 2 == 0 && LAST > 0 && LAST <= NT && NST <= kL1Stage, "map size");
+    using R = L1Runs<H, W>;
+    constexpr int WP = R::WP, Wp = R::Wp, NWIN = R::NWIN, NXS = R::NXS, HW = R::HW, NST = R::NST, RL = R::RL, RR = R::RR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
-    float *xs = smem + wave * ((NXS + 3) & ~3);
+    float *xs = smem + wave * R::TILE;
+    for (int q = NXS + lane; q < R::TILE; q += 64) xs[q] = 0.f;      // the rows a run past the map's end reads: finite, never stored
     float wb[3];
     int aoff[3];
 #pragma unroll
@@ -381,9 +392,12 @@ __device__ __forceinline__ void l1f_forward_clips(const float *__restrict__ feat
     long first;
     int count;
     l1m_clips(B, clips_per_wave, first, count);
-    const int qa = li >> 2, e = li & 3, eoff = (e >> 1) * WP + (e & 1);
-    const int wa0 = qa * NT, a_ph0 = wa0 / Wp, a_pw0 = wa0 - a_ph0 * Wp;
-    const int cnt = lq < 3 ? NT : LAST;                  // windows of the quadrant this lane stores
+    // A side: lane supplies pixel (quadrant qa = li >> 2, element e = li & 3) at tap 4j + lq; its run starts at window row RR * qa
+    const int qa = li >> 2, e = li & 3;
+    const float *abase[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) abase[j] = xs + 2 * (RR * qa) * WP + (e >> 1) * WP + (e & 1) + aoff[j];
+    const int cnt = NWIN - RL * lq < RL ? NWIN - RL * lq : RL;    // real windows of the quadrant this lane stores
     float pre[NST];
     auto fetch = [&](long b) {
 #pragma unroll
@@ -401,26 +415,22 @@ __device__ __forceinline__ void l1f_forward_clips(const float *__restrict__ feat
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (i + 1 < count) fetch(first + i + 1);
-        float *out = a1 + ((first + i) * NWIN + lq * NT) * 16 + li;
-        int a_pw = a_pw0, a_off = 2 * a_ph0 * WP + 2 * a_pw0 + eoff;
-        auto zprod = [&](int t) {
-            const int ao = (t < LAST || qa < 3) ? a_off : eoff;      // past the clip: window 0, never stored
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc = mfma16(xs[ao + aoff[j]], wb[j], acc);
-            const bool wrap = ++a_pw == Wp;
-            a_pw = wrap ? 0 : a_pw;
-            a_off += wrap ? kWrap : 2;
-            return acc;
-        };
-        f32x4 z = zprod(0);
+        float *out = a1 + ((first + i) * NWIN + RL * lq) * 16 + li;
 #pragma nounroll
-        for (int t0 = 0; t0 < NT; t0 += UN) {
+        for (int row = 0; row < RR; ++row) {            // one window row of every quadrant: Wp tiles with immediate offsets
+            const int ro = row * 2 * WP;
+            const float *ar[3] = {abase[0] + ro, abase[1] + ro, abase[2] + ro};
+            auto zprod = [&](int c) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int jt = 0; jt < UN; ++jt) {
-                const int t = t0 + jt;
-                if (NT % UN != 0 && t >= NT) continue;
-                const f32x4 zn = zprod(t + 1);          // one product past the last tile: a valid address, the result is dropped
+                for (int j = 0; j < 3; ++j) acc = mfma16(ar[j][2 * c], wb[j], acc);
+                return acc;
+            };
+            f32x4 z = zprod(0);
+#pragma unroll
+            for (int c = 0; c < Wp; ++c) {
+                const f32x4 zn = c + 1 < Wp ? zprod(c + 1) : z;       // the next tile's product is issued before this tile is finished
+                const int t = row * Wp + c;
                 const float y0 = fmaf(z[0], sc, sh), y1 = fmaf(z[1], sc, sh), y2 = fmaf(z[2], sc, sh), y3 = fmaf(z[3], sc, sh);
                 if (t < cnt) out[t * 16] = relu6f(fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
                 z = zn;

@@ -450,7 +450,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         const bool l1m = d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * kL1Stage &&
                          (d.H0 / 2) * (d.W0 / 2) <= 4 * kL1MaxTiles;
         const int cpw = std::max(1, (B + 4 * kMaxStatBlocks - 1) / (4 * kMaxStatBlocks)), nbm = (B + 4 * cpw - 1) / (4 * cpw);
-        const size_t smemm = sizeof(float) * 4 * (size_t)((((d.H0 + 2) * (d.W0 + 2)) + 3) & ~3);
+        // per-wave LDS tiles; the compile-time form of the default map reads two rows past the haloed map (kws_layer1.h: L1Runs)
+        const size_t smemm = sizeof(float) * 4 * (d.H0 == 30 && d.W0 == 20 ? (size_t)L1Runs<30, 20>::TILE : (size_t)((((d.H0 + 2) * (d.W0 + 2)) + 3) & ~3));
         const long M1 = (long)B * d.H0 * d.W0;
         BnCoef k1 = coef_of(w.coef[0], 16);
         const float *kern1 = params + m->o_k[0];
@@ -820,7 +821,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         const bool l1m = d.H0 % 2 == 0 && d.W0 % 2 == 0 && (d.H0 + 2) * (d.W0 + 2) <= 64 * kL1Stage &&
                          (d.H0 / 2) * (d.W0 / 2) <= 4 * kL1MaxTiles;
         const int cpw = std::max(1, (B + 4 * kMaxStatBlocks - 1) / (4 * kMaxStatBlocks)), nbm = (B + 4 * cpw - 1) / (4 * cpw);
-        const size_t smemm = sizeof(float) * 4 * (size_t)((((d.H0 + 2) * (d.W0 + 2)) + 3) & ~3);
+        // per-wave LDS tiles; the compile-time form of the default map reads two rows past the haloed map (kws_layer1.h: L1Runs)
+        const size_t smemm = sizeof(float) * 4 * (d.H0 == 30 && d.W0 == 20 ? (size_t)L1Runs<30, 20>::TILE : (size_t)((((d.H0 + 2) * (d.W0 + 2)) + 3) & ~3));
         const long M1 = (long)B * d.H0 * d.W0;
         BnCoef k1 = coef_of(w.coef[0], 16);
         const float *kern1 = params + m->o_k[0];

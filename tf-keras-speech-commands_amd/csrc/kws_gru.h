@@ -154,7 +154,9 @@ __global__ __launch_bounds__(192) void gru_bwd_kernel(const float *__restrict__ 
     for (int i = 0; i < 9; ++i) accU[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < WT; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float sb0 = 0.f, sb1 = 0.f;                        // bias partials of column threadIdx.x (< 144)
+    // bias partials of unit u over this lane's four clips: dz', dr', dhh, dmh_h (a per-step loop over the 16 clips of the LDS tile -- 32
+    // dependent LDS reads per thread and step -- cost 1.5 us of every step)
+    float sbz = 0.f, sbr = 0.f, sbh = 0.f, sbm = 0.f;
 
     gru_stage_x(feat, xs, b0, B, T, F, XS, drop_rate, slo, shi);
     for (int i = threadIdx.x; i < 16 * kGruU; i += 192) {
@@ -163,63 +165,105 @@ __global__ __launch_bounds__(192) void gru_bwd_kernel(const float *__restrict__ 
     }
     __syncthreads();
 
+    // the step's saved forward values (h_prev, z, r, hh, mh_h of this lane's four clips) come from global memory: they are requested
+    // one step AHEAD, under the previous step's products -- fetched at the top of their own step, the round trip was a third of the
+    // kernel (30 dependent steps x ~1.5 us)
+    float svn[4][kGruSave];
+    // unconditional loads on clamped (clip, step) addresses, masked afterwards: nothing to branch around
+    const float *svbase[4];
+    float svmask[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = 4 * lq + r;
+        const bool in = b0 + c < B;
+        svbase[r] = saved + ((long)(in ? b0 + c : b0) * T * kGruSave) * kGruU + u;
+        svmask[r] = in ? 1.f : 0.f;
+    }
+    auto fetch_saved = [&](int t) {
+        const int tc = t >= 0 ? t : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float *sv = svbase[r] + (long)tc * kGruSave * kGruU;
+#pragma unroll
+            for (int q = 0; q < kGruSave; ++q) svn[r][q] = sv[q * kGruU] * svmask[r];
+        }
+    };
+    fetch_saved(T - 1);
     int cur = 0;
     for (int t = T - 1; t >= 0; --t) {
         const float *dc = dhs + cur * 16 * kGruHS;
         float dhz[4];
+        float svc[4][kGruSave];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < kGruSave; ++q) svc[r][q] = svn[r][q];
+        fetch_saved(t - 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = 4 * lq + r;
-            float hp = 0.f, z = 0.f, rg = 0.f, hh = 0.f, mhh = 0.f;
-            if (b0 + c < B) {
-                const float *sv = saved + (((long)(b0 + c) * T + t) * kGruSave) * kGruU + u;
-                hp = sv[0]; z = sv[kGruU]; rg = sv[2 * kGruU]; hh = sv[3 * kGruU]; mhh = sv[4 * kGruU];
-            }
+            const float hp = svc[r][0], z = svc[r][1], rg = svc[r][2], hh = svc[r][3], mhh = svc[r][4];
             const float dh = dc[c * kGruHS + u];
             const float dhh = dh * (1.f - z);
-            G[c * kGruGS + u] = dh * (hp - hh) * z * (1.f - z);
-            G[c * kGruGS + kGruU + u] = dhh * mhh * rg * (1.f - rg);
+            const float gz = dh * (hp - hh) * z * (1.f - z), gr = dhh * mhh * rg * (1.f - rg), gm = dhh * rg;
+            G[c * kGruGS + u] = gz;
+            G[c * kGruGS + kGruU + u] = gr;
             G[c * kGruGS + 2 * kGruU + u] = dhh;
-            G[c * kGruGS + 3 * kGruU + u] = dhh * rg;
+            G[c * kGruGS + 3 * kGruU + u] = gm;
             Hp[c * kGruHS + u] = hp;
             dhz[r] = dh * z;
+            sbz += gz; sbr += gr; sbh += dhh; sbm += gm;     // bias gradients: column sums of G, kept per lane (clips past B contribute zeros)
         }
         __syncthreads();
-        // dh_prev = dh z + dmh U^T   (dmh = columns [0,96) and [144,192) of G)
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // Every MFMA operand of the step is read from LDS into registers FIRST (one batch of independent reads whose latencies overlap),
+        // then the products run from registers: read-then-multiply per MFMA left ~150 dependent LDS round trips in every step, and the
+        // step (4.7 us) was three times its matrix time.
+        float ga[36], hv[4], gu[9][4], gw[WT][4], xa[WT][4];
 #pragma unroll
         for (int j = 0; j < 36; ++j) {
             const int n = 4 * j + lq;
-            acc = mfma16(G[li * kGruGS + (n < 96 ? n : n + kGruU)], ut[j], acc);
+            ga[j] = G[li * kGruGS + (n < 96 ? n : n + kGruU)];            // dmh rows of this lane's clip (A operand of dh_prev)
         }
-        float *dn = dhs + (cur ^ 1) * 16 * kGruHS;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dn[(4 * lq + r) * kGruHS + u] = acc[r] + dhz[r];
-        // dU[16w + ..][:] += h_prev^T dmh   (reduction index = clip)
+        for (int j = 0; j < 4; ++j) hv[j] = Hp[(4 * j + lq) * kGruHS + u];
 #pragma unroll
         for (int nt = 0; nt < 9; ++nt) {
             const int col = 16 * nt + li, gcol = col < 96 ? col : col + kGruU;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                accU[nt] = mfma16(Hp[(4 * j + lq) * kGruHS + u], G[(4 * j + lq) * kGruGS + gcol], accU[nt]);
+            for (int j = 0; j < 4; ++j) gu[nt][j] = G[(4 * j + lq) * kGruGS + gcol];
         }
-        // dW tiles (feature rows x 144 dmx columns = the first 144 columns of G), dealt round-robin to the waves
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
-            const int tile = wave + 3 * i;
-            if (tile < MTW * 9) {
-                const int mt = tile / 9, nt = tile % 9, f = 16 * mt + li;
+            const int tile = wave + 3 * i, tl = tile < MTW * 9 ? tile : 0;
+            const int mt = tl / 9, nt = tl % 9, f = 16 * mt + li;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a = f < F ? xs[(4 * j + lq) * XS + t * F + f] : 0.f;
-                    accW[i] = mfma16(a, G[(4 * j + lq) * kGruGS + 16 * nt + li], accW[i]);
-                }
+            for (int j = 0; j < 4; ++j) {
+                gw[i][j] = G[(4 * j + lq) * kGruGS + 16 * nt + li];
+                xa[i][j] = f < F ? xs[(4 * j + lq) * XS + t * F + f] : 0.f;
             }
         }
-        if (threadIdx.x < kGruN) {
-            const int n = threadIdx.x, gcol = n < 96 ? n : n + kGruU;
-            for (int c = 0; c < 16; ++c) { sb0 += G[c * kGruGS + n]; sb1 += G[c * kGruGS + gcol]; }
+        // dh_prev = dh z + dmh U^T   (dmh = columns [0,96) and [144,192) of G); three independent accumulation chains
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            acc0 = mfma16(ga[3 * j], ut[3 * j], acc0);
+            acc1 = mfma16(ga[3 * j + 1], ut[3 * j + 1], acc1);
+            acc2 = mfma16(ga[3 * j + 2], ut[3 * j + 2], acc2);
         }
+        float *dn = dhs + (cur ^ 1) * 16 * kGruHS;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dn[(4 * lq + r) * kGruHS + u] = (acc0[r] + acc1[r]) + acc2[r] + dhz[r];
+        // dU[16w + ..][:] += h_prev^T dmh   (reduction index = clip)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)                    // j outside: consecutive MFMAs write different accumulators (no dependent back-to-back pair)
+#pragma unroll
+            for (int nt = 0; nt < 9; ++nt) accU[nt] = mfma16(hv[j], gu[nt][j], accU[nt]);
+        // dW tiles (feature rows x 144 dmx columns = the first 144 columns of G), dealt round-robin to the waves
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < WT; ++i)               // tiles past the end (wave + 3 i >= MTW * 9) multiply window-0 operands into an accumulator that is never stored
+                accW[i] = mfma16(xa[i][j], gw[i][j], accW[i]);
         cur ^= 1;
         __syncthreads();
     }
@@ -240,9 +284,18 @@ __global__ __launch_bounds__(192) void gru_bwd_kernel(const float *__restrict__ 
             }
         }
     }
-    if (threadIdx.x < kGruN) {
-        atomicAdd(db + threadIdx.x, sb0);
-        atomicAdd(db + kGruN + threadIdx.x, sb1);
+    // db0 = sums of dmx = [dz' dr' dhh], db1 = sums of dmh = [dz' dr' dmh_h]; lanes with equal li hold the same unit: reduce over lq
+    sbz += __shfl_xor(sbz, 16, 64); sbz += __shfl_xor(sbz, 32, 64);
+    sbr += __shfl_xor(sbr, 16, 64); sbr += __shfl_xor(sbr, 32, 64);
+    sbh += __shfl_xor(sbh, 16, 64); sbh += __shfl_xor(sbh, 32, 64);
+    sbm += __shfl_xor(sbm, 16, 64); sbm += __shfl_xor(sbm, 32, 64);
+    if (lq == 0) {
+        atomicAdd(db + u, sbz);
+        atomicAdd(db + kGruU + u, sbr);
+        atomicAdd(db + 2 * kGruU + u, sbh);
+        atomicAdd(db + kGruN + u, sbz);
+        atomicAdd(db + kGruN + kGruU + u, sbr);
+        atomicAdd(db + kGruN + 2 * kGruU + u, sbm);
     }
 }
 

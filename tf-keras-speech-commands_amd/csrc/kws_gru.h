@@ -129,11 +129,16 @@ __global__ __launch_bounds__(192) void gru_fwd_kernel(const float *__restrict__ 
 //   dz = dh (h_prev - hh); dhh = dh (1 - z); dr = dhh mh_h; dmh_h = dhh r; dz' = dz z(1-z); dr' = dr r(1-r)
 //   dmx = [dz' dr' dhh]; dmh = [dz' dr' dmh_h];  dh_prev = dh z + dmh U^T
 //   dW += x_t^T dmx; dU += h_prev^T dmh; db0 += sum dmx; db1 += sum dmh      (block partials -> float atomics)
+// Nine waves: waves 0-2 carry the recurrence (gate gradients G of their 16 hidden units -> LDS, then dh_prev = dh z + dmh U^T), waves 3-5
+// and 6-8 take the two weight-gradient products of the SAME step (dU: 36, dW: 24 of the step's 96 MFMAs, none of which feeds the
+// recurrence) from the G / h_prev / x tiles in LDS, between the same two barriers.  The step's critical path is then 36 MFMAs instead of 96
+// (three waves doing everything: 109 us at B = 2048; six waves, dU + dW together: 90 us).
+constexpr int kGruBwdThreads = 576;
 template <int KX>
-__global__ __launch_bounds__(192) void gru_bwd_kernel(const float *__restrict__ feat, const float *__restrict__ Uk,
-                                                       const float *__restrict__ saved, const float *__restrict__ dh_last,
-                                                       float *__restrict__ dW, float *__restrict__ dU, float *__restrict__ db,
-                                                       int B, int T, int F, float drop_rate, uint32_t slo, uint32_t shi)
+__global__ __launch_bounds__(kGruBwdThreads) void gru_bwd_kernel(const float *__restrict__ feat, const float *__restrict__ Uk,
+                                                                  const float *__restrict__ saved, const float *__restrict__ dh_last,
+                                                                  float *__restrict__ dW, float *__restrict__ dU, float *__restrict__ db,
+                                                                  int B, int T, int F, float drop_rate, uint32_t slo, uint32_t shi)
 {
     constexpr int MTW = (KX * 4 + 15) / 16;            // 16-row tiles covering the F input features
     constexpr int WT = (MTW * 9 + 2) / 3;              // dW tiles per wave
@@ -144,158 +149,168 @@ __global__ __launch_bounds__(192) void gru_bwd_kernel(const float *__restrict__ 
     float *Hp = G + 16 * kGruGS;                       // [16][kGruHS] h_prev of the step
     float *dhs = Hp + 16 * kGruHS;                     // [2][16][kGruHS]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
-    const int b0 = blockIdx.x * 16, u = 16 * wave + li;
-
-    float ut[36];                                      // B fragments of U^T restricted to dmh's 144 columns
-#pragma unroll
-    for (int j = 0; j < 36; ++j) ut[j] = Uk[u * kGruN + 4 * j + lq];
-    f32x4 accU[9], accW[WT];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) accU[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < WT; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // bias partials of unit u over this lane's four clips: dz', dr', dhh, dmh_h (a per-step loop over the 16 clips of the LDS tile -- 32
-    // dependent LDS reads per thread and step -- cost 1.5 us of every step)
-    float sbz = 0.f, sbr = 0.f, sbh = 0.f, sbm = 0.f;
+    const bool rec = wave < 3;                         // recurrence waves; waves 3-5 accumulate dU, waves 6-8 dW
+    const bool do_u = wave >= 3 && wave < 6;
+    const int w3 = wave % 3;
+    const int b0 = blockIdx.x * 16, u = 16 * w3 + li;
 
     gru_stage_x(feat, xs, b0, B, T, F, XS, drop_rate, slo, shi);
-    for (int i = threadIdx.x; i < 16 * kGruU; i += 192) {
+    for (int i = threadIdx.x; i < 16 * kGruU; i += kGruBwdThreads) {
         const int c = i / kGruU, k = i % kGruU;
         dhs[c * kGruHS + k] = (b0 + c < B) ? dh_last[(long)(b0 + c) * kGruU + k] : 0.f;
     }
     __syncthreads();
 
-    // the step's saved forward values (h_prev, z, r, hh, mh_h of this lane's four clips) come from global memory: they are requested
-    // one step AHEAD, under the previous step's products -- fetched at the top of their own step, the round trip was a third of the
-    // kernel (30 dependent steps x ~1.5 us)
-    float svn[4][kGruSave];
-    // unconditional loads on clamped (clip, step) addresses, masked afterwards: nothing to branch around
-    const float *svbase[4];
-    float svmask[4];
+    if (rec) {
+        float ut[36];                                  // B fragments of U^T restricted to dmh's 144 columns
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int c = 4 * lq + r;
-        const bool in = b0 + c < B;
-        svbase[r] = saved + ((long)(in ? b0 + c : b0) * T * kGruSave) * kGruU + u;
-        svmask[r] = in ? 1.f : 0.f;
-    }
-    auto fetch_saved = [&](int t) {
-        const int tc = t >= 0 ? t : 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float *sv = svbase[r] + (long)tc * kGruSave * kGruU;
-#pragma unroll
-            for (int q = 0; q < kGruSave; ++q) svn[r][q] = sv[q * kGruU] * svmask[r];
-        }
-    };
-    fetch_saved(T - 1);
-    int cur = 0;
-    for (int t = T - 1; t >= 0; --t) {
-        const float *dc = dhs + cur * 16 * kGruHS;
-        float dhz[4];
-        float svc[4][kGruSave];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int q = 0; q < kGruSave; ++q) svc[r][q] = svn[r][q];
-        fetch_saved(t - 1);
+        for (int j = 0; j < 36; ++j) ut[j] = Uk[u * kGruN + 4 * j + lq];
+        // bias partials of unit u over this lane's four clips: dz', dr', dhh, dmh_h
+        float sbz = 0.f, sbr = 0.f, sbh = 0.f, sbm = 0.f;
+        // the step's saved forward values (h_prev, z, r, hh, mh_h of this lane's four clips) come from global memory: they are requested
+        // one step AHEAD, under the previous step's products, by unconditional loads on clamped (clip, step) addresses, masked afterwards
+        float svn[4][kGruSave];
+        const float *svbase[4];
+        float svmask[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = 4 * lq + r;
-            const float hp = svc[r][0], z = svc[r][1], rg = svc[r][2], hh = svc[r][3], mhh = svc[r][4];
-            const float dh = dc[c * kGruHS + u];
-            const float dhh = dh * (1.f - z);
-            const float gz = dh * (hp - hh) * z * (1.f - z), gr = dhh * mhh * rg * (1.f - rg), gm = dhh * rg;
-            G[c * kGruGS + u] = gz;
-            G[c * kGruGS + kGruU + u] = gr;
-            G[c * kGruGS + 2 * kGruU + u] = dhh;
-            G[c * kGruGS + 3 * kGruU + u] = gm;
-            Hp[c * kGruHS + u] = hp;
-            dhz[r] = dh * z;
-            sbz += gz; sbr += gr; sbh += dhh; sbm += gm;     // bias gradients: column sums of G, kept per lane (clips past B contribute zeros)
+            const bool in = b0 + c < B;
+            svbase[r] = saved + ((long)(in ? b0 + c : b0) * T * kGruSave) * kGruU + u;
+            svmask[r] = in ? 1.f : 0.f;
         }
-        __syncthreads();
-        // Every MFMA operand of the step is read from LDS into registers FIRST (one batch of independent reads whose latencies overlap),
-        // then the products run from registers: read-then-multiply per MFMA left ~150 dependent LDS round trips in every step, and the
-        // step (4.7 us) was three times its matrix time.
-        float ga[36], hv[4], gu[9][4], gw[WT][4], xa[WT][4];
+        auto fetch_saved = [&](int t) {
+            const int tc = t >= 0 ? t : 0;
 #pragma unroll
-        for (int j = 0; j < 36; ++j) {
-            const int n = 4 * j + lq;
-            ga[j] = G[li * kGruGS + (n < 96 ? n : n + kGruU)];            // dmh rows of this lane's clip (A operand of dh_prev)
+            for (int r = 0; r < 4; ++r) {
+                const float *sv = svbase[r] + (long)tc * kGruSave * kGruU;
+#pragma unroll
+                for (int q = 0; q < kGruSave; ++q) svn[r][q] = sv[q * kGruU] * svmask[r];
+            }
+        };
+        fetch_saved(T - 1);
+        int cur = 0;
+        for (int t = T - 1; t >= 0; --t) {
+            const float *dc = dhs + cur * 16 * kGruHS;
+            float dhz[4], svc[4][kGruSave];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < kGruSave; ++q) svc[r][q] = svn[r][q];
+            fetch_saved(t - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * lq + r;
+                const float hp = svc[r][0], z = svc[r][1], rg = svc[r][2], hh = svc[r][3], mhh = svc[r][4];
+                const float dh = dc[c * kGruHS + u];
+                const float dhh = dh * (1.f - z);
+                const float gz = dh * (hp - hh) * z * (1.f - z), gr = dhh * mhh * rg * (1.f - rg), gm = dhh * rg;
+                G[c * kGruGS + u] = gz;
+                G[c * kGruGS + kGruU + u] = gr;
+                G[c * kGruGS + 2 * kGruU + u] = dhh;
+                G[c * kGruGS + 3 * kGruU + u] = gm;
+                Hp[c * kGruHS + u] = hp;
+                dhz[r] = dh * z;
+                sbz += gz; sbr += gr; sbh += dhh; sbm += gm;     // bias gradients: column sums of G (clips past B contribute zeros)
+            }
+            __syncthreads();                           // G, Hp of step t complete (the other waves start their products)
+            // dh_prev = dh z + dmh U^T   (dmh = columns [0,96) and [144,192) of G): operands in one batch, three accumulation chains
+            float ga[36];
+#pragma unroll
+            for (int j = 0; j < 36; ++j) {
+                const int n = 4 * j + lq;
+                ga[j] = G[li * kGruGS + (n < 96 ? n : n + kGruU)];
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                acc0 = mfma16(ga[3 * j], ut[3 * j], acc0);
+                acc1 = mfma16(ga[3 * j + 1], ut[3 * j + 1], acc1);
+                acc2 = mfma16(ga[3 * j + 2], ut[3 * j + 2], acc2);
+            }
+            float *dn = dhs + (cur ^ 1) * 16 * kGruHS;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dn[(4 * lq + r) * kGruHS + u] = (acc0[r] + acc1[r]) + acc2[r] + dhz[r];
+            cur ^= 1;
+            __syncthreads();                           // dh of step t-1 complete; G / Hp may be overwritten
         }
+        // db0 = sums of dmx = [dz' dr' dhh], db1 = sums of dmh = [dz' dr' dmh_h]; lanes with equal li hold the same unit: reduce over lq
+        sbz += __shfl_xor(sbz, 16, 64); sbz += __shfl_xor(sbz, 32, 64);
+        sbr += __shfl_xor(sbr, 16, 64); sbr += __shfl_xor(sbr, 32, 64);
+        sbh += __shfl_xor(sbh, 16, 64); sbh += __shfl_xor(sbh, 32, 64);
+        sbm += __shfl_xor(sbm, 16, 64); sbm += __shfl_xor(sbm, 32, 64);
+        if (lq == 0) {
+            atomicAdd(db + u, sbz);
+            atomicAdd(db + kGruU + u, sbr);
+            atomicAdd(db + 2 * kGruU + u, sbh);
+            atomicAdd(db + kGruN + u, sbz);
+            atomicAdd(db + kGruN + kGruU + u, sbr);
+            atomicAdd(db + kGruN + 2 * kGruU + u, sbm);
+        }
+    } else {
+        f32x4 accU[9], accW[WT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hv[j] = Hp[(4 * j + lq) * kGruHS + u];
+        for (int i = 0; i < 9; ++i) accU[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 9; ++nt) {
-            const int col = 16 * nt + li, gcol = col < 96 ? col : col + kGruU;
+        for (int i = 0; i < WT; ++i) accW[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = T - 1; t >= 0; --t) {
+            __syncthreads();                           // G, Hp of step t complete
+            // every operand of the step's products in one batch of LDS reads, then the products from registers
+            if (do_u) {
+                float hv[4], gu[9][4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gu[nt][j] = G[(4 * j + lq) * kGruGS + gcol];
+                for (int j = 0; j < 4; ++j) hv[j] = Hp[(4 * j + lq) * kGruHS + u];
+#pragma unroll
+                for (int nt = 0; nt < 9; ++nt) {
+                    const int col = 16 * nt + li, gcol = col < 96 ? col : col + kGruU;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gu[nt][j] = G[(4 * j + lq) * kGruGS + gcol];
+                }
+                // dU[16w + ..][:] += h_prev^T dmh (reduction index = clip); j outside: consecutive MFMAs write different accumulators
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < 9; ++nt) accU[nt] = mfma16(hv[j], gu[nt][j], accU[nt]);
+            } else {
+                float gw[WT][4], xa[WT][4];
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    const int tile = w3 + 3 * i, tl = tile < MTW * 9 ? tile : 0;
+                    const int mt = tl / 9, nt = tl % 9, f = 16 * mt + li;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        gw[i][j] = G[(4 * j + lq) * kGruGS + 16 * nt + li];
+                        xa[i][j] = f < F ? xs[(4 * j + lq) * XS + t * F + f] : 0.f;
+                    }
+                }
+                // dW tiles (feature rows x 144 dmx columns = the first 144 columns of G), dealt round-robin to the three waves; tiles past
+                // the end multiply tile-0 operands into an accumulator that is never stored
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < WT; ++i) accW[i] = mfma16(xa[i][j], gw[i][j], accW[i]);
+            }
+            __syncthreads();                           // the recurrence waves may overwrite G / Hp
+        }
+        // D layout: row = 4*lq + r, col = li
+        if (do_u) {
+#pragma unroll
+            for (int nt = 0; nt < 9; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicAdd(dU + (16 * w3 + 4 * lq + r) * kGruN + 16 * nt + li, accU[nt][r]);
         }
 #pragma unroll
         for (int i = 0; i < WT; ++i) {
-            const int tile = wave + 3 * i, tl = tile < MTW * 9 ? tile : 0;
-            const int mt = tl / 9, nt = tl % 9, f = 16 * mt + li;
+            const int tile = w3 + 3 * i;
+            if (!do_u && tile < MTW * 9) {
+                const int mt = tile / 9, nt = tile % 9;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                gw[i][j] = G[(4 * j + lq) * kGruGS + 16 * nt + li];
-                xa[i][j] = f < F ? xs[(4 * j + lq) * XS + t * F + f] : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * mt + 4 * lq + r;
+                    if (f < F) atomicAdd(dW + f * kGruN + 16 * nt + li, accW[i][r]);
+                }
             }
         }
-        // dh_prev = dh z + dmh U^T   (dmh = columns [0,96) and [144,192) of G); three independent accumulation chains
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            acc0 = mfma16(ga[3 * j], ut[3 * j], acc0);
-            acc1 = mfma16(ga[3 * j + 1], ut[3 * j + 1], acc1);
-            acc2 = mfma16(ga[3 * j + 2], ut[3 * j + 2], acc2);
-        }
-        float *dn = dhs + (cur ^ 1) * 16 * kGruHS;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dn[(4 * lq + r) * kGruHS + u] = (acc0[r] + acc1[r]) + acc2[r] + dhz[r];
-        // dU[16w + ..][:] += h_prev^T dmh   (reduction index = clip)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)                    // j outside: consecutive MFMAs write different accumulators (no dependent back-to-back pair)
-#pragma unroll
-            for (int nt = 0; nt < 9; ++nt) accU[nt] = mfma16(hv[j], gu[nt][j], accU[nt]);
-        // dW tiles (feature rows x 144 dmx columns = the first 144 columns of G), dealt round-robin to the waves
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < WT; ++i)               // tiles past the end (wave + 3 i >= MTW * 9) multiply window-0 operands into an accumulator that is never stored
-                accW[i] = mfma16(xa[i][j], gw[i][j], accW[i]);
-        cur ^= 1;
-        __syncthreads();
-    }
-    // D layout: row = 4*lq + r, col = li
-#pragma unroll
-    for (int nt = 0; nt < 9; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(dU + (16 * wave + 4 * lq + r) * kGruN + 16 * nt + li, accU[nt][r]);
-#pragma unroll
-    for (int i = 0; i < WT; ++i) {
-        const int tile = wave + 3 * i;
-        if (tile < MTW * 9) {
-            const int mt = tile / 9, nt = tile % 9;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mt + 4 * lq + r;
-                if (f < F) atomicAdd(dW + f * kGruN + 16 * nt + li, accW[i][r]);
-            }
-        }
-    }
-    // db0 = sums of dmx = [dz' dr' dhh], db1 = sums of dmh = [dz' dr' dmh_h]; lanes with equal li hold the same unit: reduce over lq
-    sbz += __shfl_xor(sbz, 16, 64); sbz += __shfl_xor(sbz, 32, 64);
-    sbr += __shfl_xor(sbr, 16, 64); sbr += __shfl_xor(sbr, 32, 64);
-    sbh += __shfl_xor(sbh, 16, 64); sbh += __shfl_xor(sbh, 32, 64);
-    sbm += __shfl_xor(sbm, 16, 64); sbm += __shfl_xor(sbm, 32, 64);
-    if (lq == 0) {
-        atomicAdd(db + u, sbz);
-        atomicAdd(db + kGruU + u, sbr);
-        atomicAdd(db + 2 * kGruU + u, sbh);
-        atomicAdd(db + kGruN + u, sbz);
-        atomicAdd(db + kGruN + kGruU + u, sbr);
-        atomicAdd(db + kGruN + 2 * kGruU + u, sbm);
     }
 }
 

@@ -99,7 +99,7 @@ int launch_bwd(const kws_model *m, const float *feat, int B, const float *params
     if (smem > 64 * 1024)
         KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gru_bwd_kernel<KX>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    KWS_LAUNCH("gru_bwd_kernel", gru_bwd_kernel<KX>, dim3(blocks_for(B, 16)), dim3(192), smem, s, feat, params + m->o_ru, w.saved,
+    KWS_LAUNCH("gru_bwd_kernel", gru_bwd_kernel<KX>, dim3(blocks_for(B, 16)), dim3(kGruBwdThreads), smem, s, feat, params + m->o_ru, w.saved,
                w.dh_last, grads + m->o_rk, grads + m->o_ru, grads + m->o_rb, B, T, F, rate, slo, shi);
     KWS_LAUNCH_CHECK("gru_bwd_kernel");
     return KWS_OK;

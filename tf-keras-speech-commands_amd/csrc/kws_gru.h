@@ -20,7 +20,12 @@ constexpr int kGruHS = 50;                // LDS row stride of a 48-wide state t
 constexpr int kGruGS = 210;               // row stride of the 192-wide gradient tile (== 18 mod 32)
 constexpr int kGruSave = 5;               // saved per (clip, step): h_prev, z, r, hh, mh_h
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// 1 / (1 + e^-x) on the hardware exp2 / reciprocal (each within ~1 ulp; the library expf + IEEE division cost ~60 instructions per gate value,
+// a third of a recurrent step that one wave per SIMD issues alone).  e^-x overflows to inf for x < -88 -> 0, underflows to 0 for x > 88 -> 1.
+__device__ __forceinline__ float sigmoidf_(float x)
+{
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
 
 __host__ __device__ inline int gru_xstride(int T, int F)
 {
@@ -85,20 +90,28 @@ __global__ __launch_bounds__(192) void gru_fwd_kernel(const float *__restrict__ 
     for (int t = 0; t < T; ++t) {
         f32x4 az = {0.f, 0.f, 0.f, 0.f}, ar = az, axh = az, ahh = az;
         const float *hc = hs + cur * 16 * kGruHS;
+        // every LDS operand of the step in one batch (independent reads whose latencies overlap), then the products from registers
+        float xa[KX], ha[12], hpv[4];
 #pragma unroll
         for (int j = 0; j < KX; ++j) {
             const int k = 4 * j + lq;
-            const float a = k < F ? xs[li * XS + t * F + k] : 0.f;
-            az = mfma16(a, wz[j], az);
-            ar = mfma16(a, wr[j], ar);
-            axh = mfma16(a, wh[j], axh);
+            xa[j] = k < F ? xs[li * XS + t * F + k] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 12; ++j) ha[j] = hc[li * kGruHS + 4 * j + lq];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hpv[r] = hc[(4 * lq + r) * kGruHS + u];
+#pragma unroll
+        for (int j = 0; j < KX; ++j) {
+            az = mfma16(xa[j], wz[j], az);
+            ar = mfma16(xa[j], wr[j], ar);
+            axh = mfma16(xa[j], wh[j], axh);
         }
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
-            const float a = hc[li * kGruHS + 4 * j + lq];
-            az = mfma16(a, uz[j], az);
-            ar = mfma16(a, ur[j], ar);
-            ahh = mfma16(a, uh[j], ahh);
+            az = mfma16(ha[j], uz[j], az);
+            ar = mfma16(ha[j], ur[j], ar);
+            ahh = mfma16(ha[j], uh[j], ahh);
         }
         float *hn = hs + (cur ^ 1) * 16 * kGruHS;
 #pragma unroll
@@ -107,7 +120,7 @@ __global__ __launch_bounds__(192) void gru_fwd_kernel(const float *__restrict__ 
             const float z = sigmoidf_(az[r] + bz), rg = sigmoidf_(ar[r] + br);
             const float mhh = ahh[r] + bhh;
             const float hh = axh[r] + bxh + rg * mhh;
-            const float hp = hc[c * kGruHS + u];
+            const float hp = hpv[r];
             hn[c * kGruHS + u] = z * hp + (1.f - z) * hh;
             if (SAVE && b0 + c < B) {
                 float *sv = saved + (((long)(b0 + c) * T + t) * kGruSave) * kGruU + u;

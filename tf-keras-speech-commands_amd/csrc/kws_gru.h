@@ -51,79 +51,86 @@ __device__ __forceinline__ void gru_stage_x(const float *__restrict__ feat, floa
     }
 }
 
+// Nine waves: wave w owns ONE 16-column tile of the 144 gate columns (gate w / 3 of hidden units 16 (w % 3) ..), i.e. 12 + KX MFMAs per step
+// instead of 36 + 3 KX in a wave that owns all three gates of its units.  The pre-activations go through an LDS tile (z | r | x-part of
+// hh | h-part of hh), and after a barrier all 576 threads apply the gate arithmetic to the 16 x 48 outputs.  Two barriers per step, but the
+// step's dependent chain is a third as long (65 -> see DESIGN.md for the measured time); the arithmetic per output is unchanged.
+constexpr int kGruFwdThreads = 768;     // nine product waves + three more so that the gate arithmetic is one output per thread
+constexpr int kGruPS = 50;                // row stride of a pre-activation plane
 template <int KX, bool SAVE>
-__global__ __launch_bounds__(192) void gru_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ Wk,
-                                                       const float *__restrict__ Uk, const float *__restrict__ bias,
-                                                       float *__restrict__ h_out, float *__restrict__ saved, int B, int T,
-                                                       int F, float drop_rate, uint32_t slo, uint32_t shi)
+__global__ __launch_bounds__(kGruFwdThreads) void gru_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ Wk,
+                                                                  const float *__restrict__ Uk, const float *__restrict__ bias,
+                                                                  float *__restrict__ h_out, float *__restrict__ saved, int B, int T,
+                                                                  int F, float drop_rate, uint32_t slo, uint32_t shi)
 {
     extern __shared__ float gsm[];
     const int XS = gru_xstride(T, F);
     float *xs = gsm;                       // [16][XS]
     float *hs = gsm + 16 * XS;             // [2][16][kGruHS]
+    float *P = hs + 2 * 16 * kGruHS;       // [4][16][kGruPS]: z, r, x-part of hh, h-part of hh (biases included)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
-    const int b0 = blockIdx.x * 16, u = 16 * wave + li;
+    const bool mm = wave < 9;               // product waves
+    const int gate = mm ? wave / 3 : 0, b0 = blockIdx.x * 16, u = 16 * (wave % 3) + li, col = gate * kGruU + u;
 
-    float wz[KX], wr[KX], wh[KX], uz[12], ur[12], uh[12];
+    float wg[KX], ug[12];
 #pragma unroll
     for (int j = 0; j < KX; ++j) {
         const int k = 4 * j + lq;
-        wz[j] = k < F ? Wk[k * kGruN + u] : 0.f;
-        wr[j] = k < F ? Wk[k * kGruN + kGruU + u] : 0.f;
-        wh[j] = k < F ? Wk[k * kGruN + 2 * kGruU + u] : 0.f;
+        wg[j] = k < F ? Wk[k * kGruN + col] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-        const int k = 4 * j + lq;
-        uz[j] = Uk[k * kGruN + u];
-        ur[j] = Uk[k * kGruN + kGruU + u];
-        uh[j] = Uk[k * kGruN + 2 * kGruU + u];
-    }
-    const float bz = bias[u] + bias[kGruN + u], br = bias[kGruU + u] + bias[kGruN + kGruU + u];
-    const float bxh = bias[2 * kGruU + u], bhh = bias[kGruN + 2 * kGruU + u];
+    for (int j = 0; j < 12; ++j) ug[j] = Uk[(4 * j + lq) * kGruN + col];
+    // z, r: one pre-activation with both biases; hh keeps its x-part (bias b0) and h-part (bias b1) apart: hh = mx_h + r * mh_h
+    const float bx = gate < 2 ? bias[col] + bias[kGruN + col] : bias[col], bh = gate < 2 ? 0.f : bias[kGruN + col];
 
     gru_stage_x(feat, xs, b0, B, T, F, XS, drop_rate, slo, shi);
-    for (int i = threadIdx.x; i < 2 * 16 * kGruHS; i += 192) hs[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * 16 * kGruHS; i += kGruFwdThreads) hs[i] = 0.f;
     __syncthreads();
 
     int cur = 0;
     for (int t = 0; t < T; ++t) {
-        f32x4 az = {0.f, 0.f, 0.f, 0.f}, ar = az, axh = az, ahh = az;
         const float *hc = hs + cur * 16 * kGruHS;
-        // every LDS operand of the step in one batch (independent reads whose latencies overlap), then the products from registers
-        float xa[KX], ha[12], hpv[4];
+        if (mm) {
+            float xa[KX], ha[12];
 #pragma unroll
-        for (int j = 0; j < KX; ++j) {
-            const int k = 4 * j + lq;
-            xa[j] = k < F ? xs[li * XS + t * F + k] : 0.f;
+            for (int j = 0; j < KX; ++j) {
+                const int k = 4 * j + lq;
+                xa[j] = k < F ? xs[li * XS + t * F + k] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 12; ++j) ha[j] = hc[li * kGruHS + 4 * j + lq];
+            // x-part and two halves of the h-part in separate accumulators: three short dependent chains instead of one of 12 + KX
+            f32x4 ax = {0.f, 0.f, 0.f, 0.f}, ah0 = ax, ah1 = ax;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (j < KX) ax = mfma16(xa[j], wg[j], ax);
+                ah0 = mfma16(ha[j], ug[j], ah0);
+                ah1 = mfma16(ha[6 + j], ug[6 + j], ah1);
+            }
+#pragma unroll
+            for (int j = 6; j < KX; ++j) ax = mfma16(xa[j], wg[j], ax);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * lq + r;
+                const float hsum = ah0[r] + ah1[r];
+                if (gate < 2) P[(gate * 16 + c) * kGruPS + u] = (ax[r] + hsum) + bx;
+                else {
+                    P[(2 * 16 + c) * kGruPS + u] = ax[r] + bx;
+                    P[(3 * 16 + c) * kGruPS + u] = hsum + bh;
+                }
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 12; ++j) ha[j] = hc[li * kGruHS + 4 * j + lq];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hpv[r] = hc[(4 * lq + r) * kGruHS + u];
-#pragma unroll
-        for (int j = 0; j < KX; ++j) {
-            az = mfma16(xa[j], wz[j], az);
-            ar = mfma16(xa[j], wr[j], ar);
-            axh = mfma16(xa[j], wh[j], axh);
-        }
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            az = mfma16(ha[j], uz[j], az);
-            ar = mfma16(ha[j], ur[j], ar);
-            ahh = mfma16(ha[j], uh[j], ahh);
-        }
+        __syncthreads();
         float *hn = hs + (cur ^ 1) * 16 * kGruHS;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 4 * lq + r;
-            const float z = sigmoidf_(az[r] + bz), rg = sigmoidf_(ar[r] + br);
-            const float mhh = ahh[r] + bhh;
-            const float hh = axh[r] + bxh + rg * mhh;
-            const float hp = hpv[r];
-            hn[c * kGruHS + u] = z * hp + (1.f - z) * hh;
+        for (int e = threadIdx.x; e < 16 * kGruU; e += kGruFwdThreads) {
+            const int c = e / kGruU, k = e - c * kGruU;
+            const float z = sigmoidf_(P[c * kGruPS + k]), rg = sigmoidf_(P[(16 + c) * kGruPS + k]);
+            const float mhh = P[(48 + c) * kGruPS + k];
+            const float hh = P[(32 + c) * kGruPS + k] + rg * mhh;
+            const float hp = hc[c * kGruHS + k];
+            hn[c * kGruHS + k] = z * hp + (1.f - z) * hh;
             if (SAVE && b0 + c < B) {
-                float *sv = saved + (((long)(b0 + c) * T + t) * kGruSave) * kGruU + u;
+                float *sv = saved + (((long)(b0 + c) * T + t) * kGruSave) * kGruU + k;
                 sv[0] = hp; sv[kGruU] = z; sv[2 * kGruU] = rg; sv[3 * kGruU] = hh; sv[4 * kGruU] = mhh;
             }
         }
@@ -131,10 +138,9 @@ __global__ __launch_bounds__(192) void gru_fwd_kernel(const float *__restrict__ 
         __syncthreads();
     }
     const float *hf = hs + cur * 16 * kGruHS;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int c = 4 * lq + r;
-        if (b0 + c < B) h_out[(long)(b0 + c) * kGruU + u] = hf[c * kGruHS + u];
+    for (int e = threadIdx.x; e < 16 * kGruU; e += kGruFwdThreads) {
+        const int c = e / kGruU, k = e - c * kGruU;
+        if (b0 + c < B) h_out[(long)(b0 + c) * kGruU + k] = hf[c * kGruHS + k];
     }
 }
 
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(kGruBwdThreads) void gru_bwd_kernel(const float *__
     }
 }
 
-inline size_t gru_fwd_smem(int T, int F) { return sizeof(float) * (size_t)(16 * gru_xstride(T, F) + 2 * 16 * kGruHS); }
+inline size_t gru_fwd_smem(int T, int F) { return sizeof(float) * (size_t)(16 * gru_xstride(T, F) + 2 * 16 * kGruHS + 4 * 16 * kGruPS); }
 inline size_t gru_bwd_smem(int T, int F)
 {
     return sizeof(float) * (size_t)(16 * gru_xstride(T, F) + 16 * kGruGS + 16 * kGruHS + 2 * 16 * kGruHS);

@@ -66,13 +66,13 @@ int launch_fwd(const kws_model *m, const float *feat, int B, const float *params
         if (smem > 64 * 1024)
             KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gru_fwd_kernel<KX, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        KWS_LAUNCH("gru_fwd_kernel", (gru_fwd_kernel<KX, true>), dim3(blocks_for(B, 16)), dim3(192), smem, s, feat, params + m->o_rk,
+        KWS_LAUNCH("gru_fwd_kernel", (gru_fwd_kernel<KX, true>), dim3(blocks_for(B, 16)), dim3(kGruFwdThreads), smem, s, feat, params + m->o_rk,
                    params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi);
     } else {
         if (smem > 64 * 1024)
             KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gru_fwd_kernel<KX, false>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        KWS_LAUNCH("gru_fwd_kernel", (gru_fwd_kernel<KX, false>), dim3(blocks_for(B, 16)), dim3(192), smem, s, feat, params + m->o_rk,
+        KWS_LAUNCH("gru_fwd_kernel", (gru_fwd_kernel<KX, false>), dim3(blocks_for(B, 16)), dim3(kGruFwdThreads), smem, s, feat, params + m->o_rk,
                    params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi);
     }
     KWS_LAUNCH_CHECK("gru_fwd_kernel");

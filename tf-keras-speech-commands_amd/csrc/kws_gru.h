@@ -14,6 +14,15 @@
 
 namespace kws {
 
+// tanh(x) = (1 - e^-2|x|) / (1 + e^-2|x|) with the sign of x, on the same two hardware instructions (absolute error ~2e-7; the form
+// 2 sigmoid(2x) - 1 cancels for small x)
+__device__ __forceinline__ float tanh_fast_(float x)
+{
+    const float e = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(x));
+    const float t = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+    return copysignf(t, x);
+}
+
 constexpr int kGruU = 48;                 // recurrent_units (classifier/model.py:27)
 constexpr int kGruN = 3 * kGruU;          // 144 gate columns
 constexpr int kGruHS = 50;                // LDS row stride of a 48-wide state tile (== 18 mod 32: conflict-free A reads)

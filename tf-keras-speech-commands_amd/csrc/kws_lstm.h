@@ -73,8 +73,8 @@ __global__ __launch_bounds__(192) void lstm_fwd_kernel(const float *__restrict__
         for (int r = 0; r < 4; ++r) {
             const int c = 4 * lq + r;
             const float ig = sigmoidf_(acc[0][r] + bq[0]), fg = sigmoidf_(acc[1][r] + bq[1]);
-            const float gg = tanhf(acc[2][r] + bq[2]), og = sigmoidf_(acc[3][r] + bq[3]);
-            const float cp = cst[r], cn = fg * cp + ig * gg, tc = tanhf(cn);
+            const float gg = tanh_fast_(acc[2][r] + bq[2]), og = sigmoidf_(acc[3][r] + bq[3]);
+            const float cp = cst[r], cn = fg * cp + ig * gg, tc = tanh_fast_(cn);
             const float hp = hc[c * kGruHS + u];
             cst[r] = cn;
             hn[c * kGruHS + u] = og * tc;
@@ -134,18 +134,41 @@ __global__ __launch_bounds__(192) void lstm_bwd_kernel(const float *__restrict__
     __syncthreads();
 
     float dcs[4] = {0.f, 0.f, 0.f, 0.f};               // dL/dc of (clip 4 lq + r, unit u), carried backwards
+    // the step's saved forward values come from global memory: requested one step AHEAD by unconditional loads on clamped (clip, step)
+    // addresses, masked afterwards (kws_gru.h: gru_bwd_kernel has the measurements)
+    float svn[4][kLstmSave];
+    const float *svbase[4];
+    float svmask[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = 4 * lq + r;
+        const bool in = b0 + c < B;
+        svbase[r] = saved + ((long)(in ? b0 + c : b0) * T * kLstmSave) * kGruU + u;
+        svmask[r] = in ? 1.f : 0.f;
+    }
+    auto fetch_saved = [&](int t) {
+        const int tcl = t >= 0 ? t : 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float *sv = svbase[r] + (long)tcl * kLstmSave * kGruU;
+#pragma unroll
+            for (int q = 0; q < kLstmSave; ++q) svn[r][q] = sv[q * kGruU] * svmask[r];
+        }
+    };
+    fetch_saved(T - 1);
     int cur = 0;
     for (int t = T - 1; t >= 0; --t) {
         const float *dcur = dhs + cur * 16 * kGruHS;
+        float svc[4][kLstmSave];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < kLstmSave; ++q) svc[r][q] = svn[r][q];
+        fetch_saved(t - 1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = 4 * lq + r;
-            float hp = 0.f, cp = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, tc = 0.f;
-            if (b0 + c < B) {
-                const float *sv = saved + (((long)(b0 + c) * T + t) * kLstmSave) * kGruU + u;
-                hp = sv[0]; cp = sv[kGruU]; ig = sv[2 * kGruU]; fg = sv[3 * kGruU]; gg = sv[4 * kGruU]; og = sv[5 * kGruU];
-                tc = sv[6 * kGruU];
-            }
+            const float hp = svc[r][0], cp = svc[r][1], ig = svc[r][2], fg = svc[r][3], gg = svc[r][4], og = svc[r][5], tc = svc[r][6];
             const float dh = dcur[c * kGruHS + u];
             const float dc = dcs[r] + dh * og * (1.f - tc * tc);
             G[c * kGruGS + u] = dc * gg * ig * (1.f - ig);

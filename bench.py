@@ -333,6 +333,62 @@ def extra_workloads(torch, pr, feat_fn, reps):
     return out
 
 
+def self_launch(n, argv):
+    """Spawn `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <argv>` and relay it: rank 0's JSON line is the
+    only thing the ranks write to stdout, so the child's stdout IS this process's stdout; the exit code is the child's."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("self-launch: %s" % " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs between the rank processes on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """The control plane of an N-rank run without a GPU: process group (gloo), shard plan of one global batch (equal, uneven and
+    short batches), one all-reduce over the ranks.  Rank 0 prints one JSON line; a failed check is a non-zero exit code."""
+    import torch
+    import torch.distributed as dist
+    from kws_amd.parallel import DataParallel
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        return 2
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = DataParallel()
+    ok = dp.world == world and dp.rank == rank
+    plans = {}
+    for n in (args.batch * world, args.batch * world - 1, world - 1, 0):
+        lo, hi, w = dp.shard_plan(n)
+        t = torch.tensor([float(hi - lo), w, float(lo)], dtype=torch.float64)
+        rows = [torch.zeros_like(t) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(rows, t)
+        else:
+            rows = [t]
+        cover = sum(int(r[0]) for r in rows) == n and abs(sum(float(r[1]) for r in rows) - (1.0 if n else 0.0)) < 1e-12
+        contiguous = all(int(rows[i][2]) + int(rows[i][0]) == (int(rows[i + 1][2]) if i + 1 < world else n) for i in range(world))
+        ok = ok and cover and contiguous
+        plans[str(n)] = [[int(r[2]), int(r[2]) + int(r[0])] for r in rows]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "dry_run": True, "n_gpus": world, "ok": bool(ok), "shard_plans": plans,
+                          "config": {"parallelism": "dp%d" % world, "global_batch": args.batch * world}}))
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -346,7 +402,16 @@ def main():
     ap.add_argument("--extra-only", action="store_true", help="(internal) run the SURVEY 8(d) side workloads and print their JSON")
     ap.add_argument("--force-comm", action="store_true",
                     help="run the RCCL exchange (kws_allreduce_grads) even in a one-rank world: rehearsal of the N > 1 code path on one GPU")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: bring up the ranks (gloo), check the process group and the shard plan of the global batch, print a JSON line, exit")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as FRESH child processes, before this process has
+        # imported torch or touched HIP (a process that initialised the GPU must never fork / exec into ranks)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        raise SystemExit(dry_run(args))
 
     import torch
     if args.extra_only:
@@ -592,7 +657,10 @@ def main():
                           "input_pipeline": "features of batch k+1 (and their second moments for layer 1, kws_feature_moments) computed on a side stream during step k, started behind the last BatchNormalization's activation kernel (kws_train_args.overlap_event, best robust point of eight swept; all K featurizations inside the timed region)",
                           "gradient_exchange": ("kws_train_args.comm (RCCL behind the C ABI): early bucket grads[%d:] on the model's side stream behind conv4's weight gradient, "
                                                 "late bucket + BN moving statistics grouped on the main stream behind the backward pass" % split) if comm is not None else "none (one rank)",
-                          "allreduce_us": allreduce_us,
+                          "allreduce_us": allreduce_us, "rccl_ranks": comm.world if comm is not None else 0,
+                          "rccl_version": comm.rccl_version if comm is not None else None,
+                          "rccl_env": {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                                  "GPU_MAX_HW_QUEUES") if k in os.environ},
                           "train_step_hbm_roofline_frac": round(value / world * 229.8e3 / (HBM_PEAK_GBS * 1e9), 4),
                           "library_build": L.build_id().get("kws_featurize.hip")},
                "roofline": roofline, "cpu_baseline": cpu, "extra": extra, "kernel_ms_per_step": breakdown,

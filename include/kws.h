@@ -178,8 +178,8 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
  * from the weights alone -- the folded BatchNormalization coefficients, the bf16 planes of the split-precision matrix operands,
  * the fp16 weight blob of simple_cnn_lite -- once, into `ws`; every later kws_model_forward with the SAME (B, params, state, ws)
  * and precisions then skips that work (17 of 300 us per call at B = 4096 for simple_cnn).  The caller promises not to change
- * `params` / `state` in between; kws_model_invalidate_prepared (or a train step, a different forward in the same workspace,
- * kws_model_set_precision) drops the prepared state.  Recurrent models have nothing to prepare (returns KWS_OK). */
+ * `params` / `state` in between; kws_model_invalidate_prepared (or a train step, or a different forward in the same workspace)
+ * drops the prepared state; it is keyed by the model's precisions, so a forward at another precision simply does not match it.  Recurrent models have nothing to prepare (returns KWS_OK). */
 int kws_model_prepare_inference(kws_model *m, int B, const float *params, const float *state, void *ws, size_t ws_bytes, void *stream);
 int kws_model_invalidate_prepared(kws_model *m);
 
@@ -280,6 +280,12 @@ int kws_model_get_precision(const kws_model *m, int *matrix, int *infer);
  * bit-identical gradients.  Much slower at large batches; recurrent models: KWS_ERR_UNSUPPORTED. */
 int kws_model_set_deterministic(kws_model *m, int on);
 
+/* Tuning aid: where in the simple_cnn train step kws_train_args.overlap_event is recorded / overlap_callback is called.  -1 (default):
+ * the library's choice (6 = behind the last BatchNormalization's activation kernel); 0 behind the last forward convolution, 1 behind
+ * the loss, 2 behind the head's backward kernel, 3 behind the dense data gradient, 4 behind BatchNorm-4's backward, 5 behind conv4's
+ * data gradient, 7 behind the dense forward product.  Changes scheduling only, never results (tests/test_model_gpu.py). */
+int kws_model_set_overlap_point(kws_model *m, int point);
+
 /* offset (in floats) that splits `grads` into {late bucket [0, split), early bucket [split, param_count)} */
 int64_t kws_model_grad_split(const kws_model *m);
 
@@ -318,6 +324,10 @@ int kws_allreduce_grads(kws_comm *c, float *grads, int64_t n, int64_t split, flo
 enum { KWS_DT_F32 = 0, KWS_DT_F64 = 1, KWS_DT_I32 = 2, KWS_DT_I64 = 3 };
 enum { KWS_OP_SUM = 0, KWS_OP_MAX = 1, KWS_OP_AVG = 2 };
 int kws_comm_allreduce(kws_comm *c, void *buf, int64_t n, int dtype, int op, void *stream);
+/* In-place broadcast of nbytes device bytes from rank `root` on `stream`: what a data-parallel fit needs once per run (the initial
+ * weights / moving statistics, where the reference has a single model object, classifier/model.py:14-46) and once per epoch (the
+ * shuffle permutation of train.py:90, shuffle=True), so that no second communicator -- with streams of its own -- is ever built. */
+int kws_comm_broadcast(kws_comm *c, void *buf, int64_t nbytes, int root, void *stream);
 
 /* Opt-in timing of the two buckets of the most recent exchange (HIP events around each RCCL launch on the stream it was enqueued
  * on); kws_comm_last_us synchronises those events; -1 = that bucket was not issued / timing off. */

@@ -139,3 +139,29 @@ def test_two_rank_gradient_exchange(tmp_path, model_type):
         l0, l1 = np.load(os.path.join(tmp_path, "local0.npy")), np.load(os.path.join(tmp_path, "local1.npy"))
         np.testing.assert_allclose(g0, 0.5 * (l0 + l1), atol=1e-12)   # per-replica batch statistics
         assert np.abs(g0 - full).max() > 1e-6
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it starts its own two ranks (fresh processes, before anything touches a GPU);
+    --dry-run stops after the process group + shard plan checks.  This is the command line the scaling driver may use."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--batch", "4096"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["dry_run"] and out["ok"] and out["n_gpus"] == 2
+    assert out["shard_plans"]["8192"] == [[0, 4096], [4096, 8192]]
+    assert out["shard_plans"]["8191"] == [[0, 4096], [4096, 8191]]
+    assert out["shard_plans"]["1"] == [[0, 1], [1, 1]]          # an empty shard still joins the collectives
+
+
+def test_bench_refuses_mismatched_world():
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode != 0

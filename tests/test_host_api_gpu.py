@@ -217,6 +217,81 @@ def test_inference_session_end_to_end_pcm16(torch, model_type, fp16):
     np.testing.assert_array_equal(ag.cpu().numpy()[clear], want.argmax(-1)[clear])
 
 
+@pytest.mark.parametrize("model_type,fp16", [("simple_cnn", False), ("simple_cnn_lite", True)])
+def test_inference_session_follows_the_weights(torch, model_type, fp16):
+    """A graph session captured with prepared weight tables must not keep answering with the OLD weights: after set_weights (and after an
+    optimizer step) run() re-derives the tables by itself and equals a fresh eager forward of the new weights, bit for bit."""
+    from classifier.params import pr
+    from kws_amd.featurizer import Featurizer
+    from kws_amd.inference import InferenceSession
+    from kws_amd.init import init_weights
+    from kws_amd.model import DeviceModel, ModelSpec
+    B, C = 32, 12
+    spec = ModelSpec(model_type, C, pr.n_features, pr.feature_size)
+    dm = DeviceModel(spec)
+    dm.set_weights(init_weights(spec, seed=1))
+    rng = np.random.default_rng(9)
+    wav = torch.from_numpy((0.1 * rng.standard_normal((B, 16000))).astype(np.float32)).cuda()
+    feat = Featurizer(pr)
+    s = InferenceSession(dm, feat, B, use_graph=True, fp16=fp16)
+    s.wav.copy_(wav)
+    p_old = s.run()[0].clone()
+    dm.set_weights(init_weights(spec, seed=2))
+    p_new = s.run()[0].clone()
+    fresh = InferenceSession(dm, feat, B, use_graph=False, fp16=fp16)
+    fresh.wav.copy_(wav)
+    want = fresh.run()[0]
+    torch.cuda.synchronize()
+    assert not torch.equal(p_old, p_new)
+    assert torch.equal(p_new, want)
+    # an optimizer step changes the weights too
+    labels = torch.from_numpy(rng.integers(0, C, B).astype(np.int32)).cuda()
+    dm.train_fwd_bwd(feat(wav), labels, dropout_seed=3)
+    dm.adam_step(1e-2)
+    p_step = s.run()[0].clone()
+    fresh2 = InferenceSession(dm, feat, B, use_graph=False, fp16=fp16)
+    fresh2.wav.copy_(wav)
+    want2 = fresh2.run()[0]
+    torch.cuda.synchronize()
+    assert not torch.equal(p_step, p_new) and torch.equal(p_step, want2)
+
+
+def test_sessions_of_two_precisions_share_a_model(torch):
+    """An fp16 session does not switch the model's own arithmetic: an fp32 eager session, plain dm.forward calls and an fp16 session on ONE
+    simple_cnn_lite DeviceModel each keep their precision whatever order they run in."""
+    from classifier.params import pr
+    from kws_amd import lib as L
+    from kws_amd.featurizer import Featurizer
+    from kws_amd.inference import InferenceSession
+    from kws_amd.init import init_weights
+    from kws_amd.model import DeviceModel, ModelSpec
+    B, C = 32, 12
+    spec = ModelSpec("simple_cnn_lite", C, pr.n_features, pr.feature_size)
+    dm = DeviceModel(spec)
+    dm.set_weights(init_weights(spec, seed=1))
+    rng = np.random.default_rng(10)
+    wav = torch.from_numpy((0.1 * rng.standard_normal((B, 16000))).astype(np.float32)).cuda()
+    feat = Featurizer(pr)
+    x = feat(wav)
+    ref32 = dm.forward(x)[0].clone()
+    s32 = InferenceSession(dm, feat, B, use_graph=False, fp16=False)
+    s16 = InferenceSession(dm, feat, B, use_graph=False, fp16=True)
+    g16 = InferenceSession(dm, feat, B, use_graph=True, fp16=True)
+    for s in (s32, s16, g16):
+        s.wav.copy_(wav)
+    assert dm.get_precision()[1] == L.INFER_FP32                      # creating fp16 sessions left the model alone
+    a16 = s16.run()[0].clone()
+    a32 = s32.run()[0].clone()
+    b16 = g16.run()[0].clone()
+    plain = dm.forward(x)[0].clone()
+    c16 = s16.run()[0].clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a32, ref32) and torch.equal(plain, ref32)
+    assert torch.equal(a16, b16) and torch.equal(a16, c16)
+    assert not torch.equal(a16, a32)                                   # fp16 activations differ in the last bits
+    assert float((a16 - a32).abs().max()) < 2e-3
+
+
 def test_eight_example_clips_argmax_agreement(torch, golden):
     """SURVEY 8(d) substitute for the unavailable Speech Commands v2 top-1: train on a synthetic separable task through the host
     API, then run the reference's eight example clips (example/*.wav, PCM in the golden file) through featurize + predict on

@@ -41,6 +41,7 @@ struct Rccl {
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -69,6 +70,7 @@ Rccl *rccl()
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -148,11 +150,16 @@ void kws_comm_destroy(kws_comm *c)
 {
     if (!c) return;
     Rccl *r = rccl();
+    // the communicator, its events and the work still in flight belong to c->device, which need not be the caller's current one
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != c->device) (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     if (c->comm && r) (void)r->CommDestroy(c->comm);
     for (auto &t : c->t)
         if (t) (void)hipEventDestroy(t);
     (void)hipGetLastError();
+    if (cur >= 0 && cur != c->device) (void)hipSetDevice(cur);
     delete c;
 }
 
@@ -248,6 +255,18 @@ int kws_comm_allreduce(kws_comm *c, void *buf, int64_t n, int dtype, int op, voi
     default: return fail(KWS_ERR_INVALID, "unknown reduction %d", op);
     }
     KWS_RCCL_CHECK("ncclAllReduce", r->AllReduce(buf, buf, (size_t)n, dt, ro, c->comm, static_cast<hipStream_t>(stream)));
+    return KWS_OK;
+}
+
+int kws_comm_broadcast(kws_comm *c, void *buf, int64_t nbytes, int root, void *stream)
+{
+    if (!c || (!buf && nbytes > 0)) return fail(KWS_ERR_INVALID, "null argument");
+    if (nbytes < 0) return fail(KWS_ERR_INVALID, "negative count");
+    if (root < 0 || root >= c->world) return fail(KWS_ERR_INVALID, "root %d outside a world of %d", root, c->world);
+    if (nbytes == 0) return KWS_OK;
+    Rccl *r = rccl();
+    if (!r) return fail(KWS_ERR_COMM, "RCCL is not available");
+    KWS_RCCL_CHECK("ncclBroadcast", r->Broadcast(buf, buf, (size_t)nbytes, ncclInt8, root, c->comm, static_cast<hipStream_t>(stream)));
     return KWS_OK;
 }
 

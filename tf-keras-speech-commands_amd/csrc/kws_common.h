@@ -34,13 +34,23 @@ inline int fail(int code, const char *fmt, ...)
                                __FILE__, __LINE__);                                                \
     } while (0)
 
-// kernel launches do not return a status; fetch the sticky launch error instead
+// <<<>>> launches do not return a status: fetch the sticky launch error; hipExtLaunchKernel (profiled launches, launches that carry a
+// fork event) does return one, which the launch helpers park in launch_error_slot()
 #define KWS_LAUNCH_CHECK(what)                                                                  \
     do {                                                                                        \
-        hipError_t e__ = hipGetLastError();                                                     \
+        hipError_t e__ = ::kws::launch_error_slot();                                            \
+        ::kws::launch_error_slot() = hipSuccess;                                                \
+        if (e__ == hipSuccess) e__ = hipGetLastError(); else (void)hipGetLastError();           \
         if (e__ != hipSuccess)                                                                  \
             return ::kws::fail(KWS_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e__)); \
     } while (0)
+
+hipError_t &launch_error_slot();      // per host thread: first failed hipExtLaunchKernel since the last KWS_LAUNCH_CHECK
+inline void note_launch_error(hipError_t e) { if (e != hipSuccess && launch_error_slot() == hipSuccess) launch_error_slot() = e; }
+// compute units of the CURRENT device, and "this kernel may use `bytes` of dynamic LDS on the current device" -- both cached per device
+// (a process may drive several devices: kws_model keeps per-device resources)
+int device_cus();
+int ensure_dynamic_lds(const void *kernel, int bytes);
 
 // 4 KB of zeros on the current device (allocated once per device): padding rows of the convolutions are READ from here
 // instead of being masked after the load, so a fragment load has no consumer until its MFMA (the prefetch can overlap).
@@ -70,6 +80,9 @@ void prof_events(const char *name, hipEvent_t *e0, hipEvent_t *e1);   // a fresh
 struct ArmedEvent { hipEvent_t ev = nullptr; hipStream_t s = nullptr; hipEvent_t bound = nullptr; };
 ArmedEvent &armed_event();
 inline void arm_stop_event(hipEvent_t ev, hipStream_t s) { ArmedEvent &a = armed_event(); a.ev = ev; a.s = s; a.bound = nullptr; }
+// Scope guard of every function that arms events: whatever way the function is left (an early KWS_TRY / KWS_HIP_CHECK return between
+// arm_stop_event and the launch that should have carried the event), no armed event survives into an unrelated launch of this thread.
+struct DisarmOnExit { ~DisarmOnExit() { ArmedEvent &a = armed_event(); a.ev = nullptr; a.s = nullptr; a.bound = nullptr; } };
 inline bool stop_event_bound(hipEvent_t ev)      // true: the kernel launched since arm_stop_event carries ev (consumes the answer)
 {
     ArmedEvent &a = armed_event();
@@ -90,13 +103,14 @@ template <typename... KArgs, typename... Args, size_t... I>
 inline void launch_timed_impl(const char *name, void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t s,
                               std::index_sequence<I...>, Args &&...args)
 {
-    // trailing parameters the call leaves out take a zero value: every default argument of this library's kernels is nullptr / 0 / empty planes
+    // RULE: trailing parameters the call leaves out take a ZERO value (value-initialised tuple), not the kernel's C++ default argument:
+    // every default argument of this library's kernels must be nullptr / 0 / false / an empty plane struct
     std::tuple<std::remove_cv_t<KArgs>...> vals{};
     set_launch_args<0>(vals, std::forward<Args>(args)...);
     void *ptrs[sizeof...(KArgs) + 1] = {static_cast<void *>(&std::get<I>(vals))..., nullptr};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     prof_events(name, &e0, &e1);
-    (void)hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, smem, s, e0, e1, 0);
+    note_launch_error(hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, smem, s, e0, e1, 0));
 }
 // the same launch with a stop event and no timing pair (fork events, see ArmedEvent)
 template <typename... KArgs, typename... Args, size_t... I>
@@ -106,7 +120,7 @@ inline void launch_stop_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, si
     std::tuple<std::remove_cv_t<KArgs>...> vals{};
     set_launch_args<0>(vals, std::forward<Args>(args)...);
     void *ptrs[sizeof...(KArgs) + 1] = {static_cast<void *>(&std::get<I>(vals))..., nullptr};
-    (void)hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, smem, s, nullptr, stop, 0);
+    note_launch_error(hipExtLaunchKernel(reinterpret_cast<const void *>(kernel), grid, block, ptrs, smem, s, nullptr, stop, 0));
 }
 template <typename... KArgs, typename... Args>
 inline void launch_stop(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t smem, hipStream_t s, hipEvent_t stop, Args &&...args)

@@ -62,6 +62,43 @@ ArmedEvent &armed_event()
     return a;
 }
 
+hipError_t &launch_error_slot()
+{
+    static thread_local hipError_t e = hipSuccess;
+    return e;
+}
+
+int device_cus()
+{
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    hipDeviceProp_t p;
+    int n = 256;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
+    else (void)hipGetLastError();
+    cus[dev] = n;
+    return n;
+}
+
+int ensure_dynamic_lds(const void *kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, int> done;
+    int dev = 0;
+    KWS_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    int &have = done[std::make_pair(dev, kernel)];
+    if (have >= bytes) return KWS_OK;
+    KWS_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+    return KWS_OK;
+}
+
 void prof_events(const char *name, hipEvent_t *e0, hipEvent_t *e1)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);

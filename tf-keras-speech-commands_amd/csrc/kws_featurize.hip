@@ -611,8 +611,7 @@ using namespace kws;
 constexpr int kV2Bands = 20, kV2Coefs = 20;
 static bool v2_applies(const FeatDev &d)
 {
-    static const bool disabled = std::getenv("KWS_FEAT_V1") != nullptr;     // A/B switch for tools/ (not part of the API)
-    return !disabled && d.n_fft == 1024 && d.hop == 512 && d.window_eff == 1024 && !d.use_delta && d.n_filt == kV2Bands &&
+    return d.n_fft == 1024 && d.hop == 512 && d.window_eff == 1024 && !d.use_delta && d.n_filt == kV2Bands &&
            d.n_out == kV2Coefs && (d.chp2 == 12 || d.chp2 == 16 || d.chp2 == 20);
 }
 static size_t v2_smem_bytes(int chp, int waves = kV2Waves)
@@ -627,19 +626,10 @@ static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, c
 {
     constexpr int kV2Waves = WAVES;          // shadows the default: everything below is per configuration
     // persistent grid: two 12-wave blocks per CU; frames per job chosen so that the jobs divide evenly over the grid's waves
-    static const int cus = [] {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) return p.multiProcessorCount;
-        (void)hipGetLastError();
-        return 256;
-    }();
-    static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs, WAVES, TWREG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)v2_smem_bytes(CHP, WAVES));
-        return true;
-    }();
-    (void)attr;
+    const int cus = device_cus();
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs, WAVES, TWREG>),
+                                    (int)v2_smem_bytes(CHP, WAVES)))
+        return rc;
     FeatDev dd = d;
     const int bpc = d.blocks_per_cu == 1 ? 1 : 2;
     const long waves = (long)bpc * cus * kV2Waves;
@@ -803,9 +793,6 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
         return T;
     };
     const ChunkTables T1 = build_chunks(1), T2 = build_chunks(2);
-    if (std::getenv("KWS_FEAT_DEBUG"))
-        fprintf(stderr, "[kws] featurizer tables: chunk %d (padded %d, %d chunks) / even-aligned chunk %d (padded %d, %d chunks)\n", T1.ch, T1.chp,
-                T1.nlog, T2.ch, T2.chp, T2.nlog);
     const int chp = T1.chp, nlog = T1.nlog, n_filt_pad = (n_filt + 3) & ~3;
     const std::vector<int4> &chunks = T1.chunks;
     const std::vector<float> &w = T1.w;

@@ -160,17 +160,7 @@ int launch_gemm(const float *src, const float *w, const float *bias, float *dst,
 }
 
 // CUs of the current device (cached) and resident blocks per CU of a kernel at a given dynamic LDS size
-static int cu_count()
-{
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int cu_count() { return device_cus(); }
 template <typename K>
 static int resident_blocks(K kernel, int threads, size_t smem)
 {
@@ -216,10 +206,8 @@ int launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom
     if (!zp) return fail(KWS_ERR_NOMEM, "cannot allocate the zero page on this device");
     constexpr size_t stage = (size_t)3 * 32 * 4 * (TPB * tr_row_words(CIN) + tr_row_words(COUT)), tile = (size_t)CIN * COUT * sizeof(float);
     constexpr size_t smem = stage > tile ? stage : tile;
-    static const int occ = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        return resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>, 256, smem);
-    }();
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>), (int)smem)) return rc;
+    static const int occ = resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>, 256, smem);
     const long M = (long)g.B * g.Ho * g.Wo, nchunk = (M + 31) / 32;
     const int ngroups = g.KH * g.KW / TPB;
     // ranges: a multiple of 8 (one per XCD), at most one resident round, at least 4 chunks per block
@@ -304,8 +292,7 @@ int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], con
     {
         // small maps with 'same' padding: pixel-major rows let a block skip the taps that are padding for its position (kws_conv.h)
         const int P = MODE == MODE_FWD ? g.Ho * g.Wo : g.H * g.W;
-        static const bool off = getenv("KWS_NO_PMAJOR") != nullptr;
-        g.pmajor = (!off && g.KH == 3 && g.KW == 3 && P > 1 && P <= 16) ? 1 : 0;
+        g.pmajor = (g.KH == 3 && g.KW == 3 && P > 1 && P <= 16) ? 1 : 0;
     }
     static const std::string name = std::string(what) + "<" + std::to_string(CR) + "," + std::to_string(CO) + ">";
     const int o = MODE == MODE_FWD ? 3 : 0;      // forward reads the transposed planes, the data gradient the original order
@@ -394,7 +381,7 @@ static bool cnn_compact_g2(const kws_model *m, bool bf16)
     return bf16 && d.H1 * d.W1 * 8 <= 1280 && (size_t)(d.H1 / 2) * (d.W1 / 2) * 32 <= sizeof(float) * (size_t)d.H3 * d.W3 * 64;
 }
 // training in split precision: conv4 and its weight gradient form a3 from z3 on the fly (kws_conv.h: ABN / XBN); the fp32 mode keeps
-// the activation kernel (same-box A/B at B = 4096: 0.6714 -> 0.666 ms per step; KWS_NO_A3_ON_LOAD=1 is the A/B switch)
+// the activation kernel (same-box A/B at B = 4096: 0.6714 -> 0.666 ms per step)
 static bool cnn_a3_on_load(const kws_model *m, bool bf16, bool training) { return bf16 && training; }
 constexpr int kPrepSplitBlocks = 16, kPrepZeroBlocks = 16, kPrepBlocks = 3 * kPrepSplitBlocks + kPrepZeroBlocks;
 
@@ -405,6 +392,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                 uint64_t seed, hipStream_t s, float *zero_grads = nullptr, bool *zeroed = nullptr, OverlapHook *hook = nullptr,
                 const double *moments = nullptr)
 {
+    const DisarmOnExit disarm_guard;        // no armed fork event outlives this call, whichever way it returns
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};   // conv input sizes
     const int Hz[4] = {d.H0, d.H1, d.H3, d.H3}, Wz[4] = {d.W0, d.W1, d.W3, d.W3};   // conv output sizes
@@ -486,10 +474,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                    d.H0, d.W0, cpb);
     }
     bool bound6 = false;
-    static const bool a3_off = getenv("KWS_NO_A3_ON_LOAD") != nullptr;
-    const bool a3_on_load = cnn_a3_on_load(m, bf16, training) && !a3_off;
-    static const bool routed_off = getenv("KWS_NO_ROUTED_BWD") != nullptr;
-    const bool routed_bwd2 = cnn_compact_g2(m, bf16) && !routed_off;
+    const bool a3_on_load = cnn_a3_on_load(m, bf16, training);
+    const bool routed_bwd2 = cnn_compact_g2(m, bf16);
     for (int l = 1; l < 4; ++l) {
         const float *in = w.a[l - 1];
         const float *kern = params + m->o_k[l];
@@ -560,7 +546,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         if (l == 3 && hook) KWS_TRY(hook->fire(0, s));
         // overlap point 6 sits right behind this layer's activation kernel: the caller's event rides on that kernel's completion signal
         // instead of a marker packet of its own (kws_common.h: ArmedEvent)
-        const bool arm6 = l == 3 && hook && hook->wants(6) && hook->ev && getenv("KWS_NO_ARMED_EVENTS") == nullptr;
+        const bool arm6 = l == 3 && hook && hook->wants(6) && hook->ev;
         if (arm6) arm_stop_event(hook->ev, s);
         if (pool[l]) {
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
@@ -568,7 +554,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             float *zm = nullptr;
             unsigned char *ag = nullptr;
             if (l == 1 && training && routed_bwd2) { zm = w.zmax2; ag = w.arg2; }
-            if (l == 3 && training && bf16 && !routed_off) { zm = w.zmax4; ag = w.arg4; }
+            if (l == 3 && training && bf16) { zm = w.zmax4; ag = w.arg4; }
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
                                w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi, zm, ag);
         } else if (!(l == 2 && a3_on_load)) {
@@ -596,6 +582,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
 {
     // fused_head != nullptr: the head's forward pass (logits, softmax, loss, dlogits) has NOT run; the head's backward kernel does it
     // (cnn_head_fwd_fused below decides)
+    const DisarmOnExit disarm_guard;        // no armed fork event outlives this call, whichever way it returns
     const CnnDims &d = m->d;
     const int Hs[4] = {d.H0, d.H1, d.H2, d.H3}, Ws[4] = {d.W0, d.W1, d.W2, d.W3};
     const int Hz[4] = {d.H0, d.H1, d.H3, d.H3}, Wz[4] = {d.W0, d.W1, d.W3, d.W3};
@@ -613,7 +600,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     const bool det = m->deterministic != 0;
     // fork: the side stream waits for everything enqueued on s so far.  arm(ev) in front of the LAST kernel before the fork lets that
     // kernel's own completion signal be the event (kws_common.h: ArmedEvent) instead of a marker packet on the main chain
-    static const bool no_arm = getenv("KWS_NO_ARMED_EVENTS") != nullptr;
+    constexpr bool no_arm = false;
     hipEvent_t fork0_ev = nullptr;
     bool fork0_bound = false;
     auto arm = [&](int ev) { if (!no_arm) arm_stop_event(R->ev[ev], s); };
@@ -672,8 +659,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         if (hook) KWS_TRY(hook->fire(3, s));
     }
     int fused_bn3_blocks = 0;          // > 0: conv4's data gradient already did layer 3's BatchNorm-backward reduction
-    static const bool routed_off = getenv("KWS_NO_ROUTED_BWD") != nullptr;
-    const bool routed_bwd2 = cnn_compact_g2(m, mprec == 1) && !routed_off;      // the forward pass left zmax2 / arg2 (same predicate)
+    const bool routed_bwd2 = cnn_compact_g2(m, mprec == 1);      // the forward pass left zmax2 / arg2 (same predicate)
     for (int l = 3; l >= 1; --l) {
         if (hook && l == 2) KWS_TRY(hook->fire(5, s));
         const int C = kCh[l + 1];
@@ -697,7 +683,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             else if (compact_g)
                 KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_pool_kernel<true>, dim3(nblk), dim3(256), 0, s, w.z[l], w.da[1], k,
                            w.gz[l], B, Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi, reinterpret_cast<unsigned char *>(w.da[2]));
-            else if (l == 3 && mprec == 1 && !routed_off)
+            else if (l == 3 && mprec == 1)
                 KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_routed_full_kernel, dim3(nblk), dim3(256), 0, s, w.zmax4, w.arg4, da, k,
                            w.gz[l], B, Hz[l], Wz[l], C, rows, w.partial, rate, slo, shi);
             else
@@ -734,8 +720,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (int rc = fork(l)) return rc;                   // dz of layer l is final: wgrad may start on the side stream
         if (l == 3) {
             const ConvGeom g = geom3x3(B, Hs[3], Ws[3], 1);
-            static const bool a3_off = getenv("KWS_NO_A3_ON_LOAD") != nullptr;
-            if (mprec == 1 && cnn_a3_on_load(m, true, true) && !a3_off)
+            if (mprec == 1 && cnn_a3_on_load(m, true, true))
                 KWS_TRY((launch_wgrad_bf16<64, 128, 1, true, true>(w.z[2], nullptr, dk, g, s2, w.dzp, det, coef_of(w.coef[2], 64).scale)));
             else if (mprec == 1) KWS_TRY(launch_wgrad_bf16<64, 128, 1, true>(in, nullptr, dk, g, s2, w.dzp, det));
             else KWS_TRY(launch_wgrad<64, 128, 1>(in, w.gz[3], dk, g, s2, det));
@@ -894,11 +879,7 @@ static int lite_forward_f16(const kws_model *m, const float *feat, int B, const 
     a.db = params + m->o_db; a.hb = params + m->o_hb; a.blob = blob;
     a.C = m->C; a.H2 = d.H2; a.W2 = d.W2; a.H3 = d.H3; a.W3 = d.W3;
     a.pt3 = same_pad_before(d.H2, 3, 2); a.pl3 = same_pad_before(d.W2, 3, 2); a.H4 = d.H4; a.W4 = d.W4;
-    static const bool attr = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lite_back_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kF16LdsBytes);
-        return true;
-    }();
-    (void)attr;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(lite_back_f16_kernel), kF16LdsBytes)) return rc;
     const int ntile = (B + kF16Clips - 1) / kF16Clips;
     KWS_LAUNCH("lite_back_f16_kernel", lite_back_f16_kernel, dim3(std::min(ntile, cu_count())), dim3(256), (size_t)kF16LdsBytes, s, a2h, a, B, probs, argmax);
     KWS_LAUNCH_CHECK("simple_cnn_lite fp16 forward");
@@ -1228,7 +1209,8 @@ int kws_model_set_precision(kws_model *m, int matrix, int infer)
     if (infer != -1 && infer != KWS_INFER_FP32 && infer != KWS_INFER_FP16) return fail(KWS_ERR_INVALID, "unknown inference precision %d", infer);
     m->matrix_precision = matrix;
     m->infer_precision = infer;
-    m->prep = kws_model::Prepared{};
+    // the prepared state is keyed by the precisions it was derived for (prepared_for): a forward at another precision does not match it,
+    // and switching back finds it again -- unless a different forward has meanwhile used the same workspace (kws_model_forward drops it)
     return KWS_OK;
 }
 
@@ -1237,6 +1219,14 @@ int kws_model_get_precision(const kws_model *m, int *matrix, int *infer)
     if (!m) return fail(KWS_ERR_INVALID, "null argument");
     if (matrix) *matrix = matrix_prec(m);
     if (infer) *infer = infer_prec(m);
+    return KWS_OK;
+}
+
+int kws_model_set_overlap_point(kws_model *m, int point)
+{
+    if (!m) return fail(KWS_ERR_INVALID, "null argument");
+    if (point < -1 || point > 7) return fail(KWS_ERR_INVALID, "overlap point %d outside -1 .. 7", point);
+    m->overlap_point = point;
     return KWS_OK;
 }
 
@@ -1391,12 +1381,8 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     // usually 2-6 us better), behind the dense forward 0.714, behind the forward pass 0.729, behind the dense data gradient 0.704, behind
     // BatchNorm-4's backward 0.721, behind conv4's data gradient 0.699.  Behind the head's backward kernel (point 2) was the best point on two
     // boxes (0.686) and the worst on two others (0.709-0.722, whatever the hardware-queue count): the featurizer then starts together with
-    // the side stream's weight-gradient chain, and which of the two gets the chip first decides.  KWS_OVERLAP_AT = 0 .. 7 re-runs the sweep.
-    hook.at = lite ? 1 : 6;
-    {
-        static const char *ov = getenv("KWS_OVERLAP_AT");
-        if (ov && !lite) hook.at = atoi(ov);
-    }
+    // the side stream's weight-gradient chain, and which of the two gets the chip first decides.  kws_model_set_overlap_point(m, 0 .. 7) re-runs the sweep.
+    hook.at = lite ? 1 : (m->overlap_point >= 0 ? m->overlap_point : 6);     // kws_model_set_overlap_point re-runs the sweep
     rc = lite ? lite_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s)
               : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s, a->grads, &grads_zeroed, &hook, a->feat_moments);
     if (rc) return rc;
@@ -1406,8 +1392,7 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     const bool fuse_stats = !lite && head_bwd_fuses(m);
     // simple_cnn (non-deterministic mode): the head's forward pass rides in its backward kernel (kws_layers.h: head_bwd_mfma_kernel<.., FWD>):
     // one launch and the dlogits round trip less on the main chain (same-box: -11 us upper bound measured by skipping the launch)
-    static const bool head_fuse_off = getenv("KWS_NO_HEAD_FUSION") != nullptr;
-    const bool fuse_head_fwd = fuse_stats && !m->deterministic && !head_fuse_off;
+    const bool fuse_head_fwd = fuse_stats && !m->deterministic;
     if (!fuse_head_fwd) {
         rc = run_head(m, a->B, a->params, w.d1, w.loss_i, w.correct_i, a->labels, a->class_weights, a->probs, nullptr, w.dlogits,
                       a->grad_scale / (float)a->B, fuse_stats ? nullptr : a->stats, a->ignore_index, s);

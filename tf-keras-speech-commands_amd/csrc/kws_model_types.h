@@ -53,6 +53,7 @@ struct kws_model {
     int deterministic = 0;       // 1: weight gradients reduced in a fixed order (kws_model_set_deterministic)
     // kws_model_prepare_inference: the weight-derived tables of an inference forward (bf16 weight planes, folded BatchNorm
     // coefficients, fp16 weight blob) already sit in THIS workspace for THESE buffers, batch and precisions
+    int overlap_point = -1;             // kws_model_set_overlap_point: -1 = the library's choice
     struct Prepared { const float *params = nullptr, *state = nullptr; void *ws = nullptr; int B = 0, matrix = -2, infer = -2; } prep;
     bool prepared_for(const float *p, const float *st, void *w, int B, int matrix, int infer) const
     {

@@ -5,6 +5,9 @@ import os
 from .build import LIB_PATH
 
 
+ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM, ERR_WORKSPACE, ERR_COMM = -1, -2, -3, -4, -5, -6   # include/kws.h
+
+
 class KwsError(RuntimeError):
     def __init__(self, code, message):
         super().__init__("kws error %d: %s" % (code, message))
@@ -122,6 +125,7 @@ def get_lib():
     L.kws_model_set_precision.argtypes = [vp, i32, i32]
     L.kws_model_get_precision.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.kws_model_set_deterministic.argtypes = [vp, i32]
+    L.kws_model_set_overlap_point.argtypes = [vp, i32]
     L.kws_comm_unique_id.argtypes = [vp]
     L.kws_comm_init.argtypes = [i32, i32, vp, ctypes.POINTER(vp)]
     L.kws_comm_destroy.argtypes = [vp]
@@ -129,6 +133,7 @@ def get_lib():
     L.kws_comm_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.kws_allreduce_grads.argtypes = [vp, vp, i64, i64, vp, i64, f32, vp]
     L.kws_comm_allreduce.argtypes = [vp, vp, i64, i32, i32, vp]
+    L.kws_comm_broadcast.argtypes = [vp, vp, i64, i32, vp]
     L.kws_comm_timing.argtypes = [vp, i32]
     L.kws_comm_last_us.argtypes = [vp, ctypes.POINTER(f32), ctypes.POINTER(f32)]
     L.kws_prof_enable.argtypes = [i32]

@@ -102,6 +102,7 @@ class DeviceModel(object):
         # the model's side stream exists from here on: before any communicator / pipeline creates streams of its own (kws_model_bind_device)
         _l.check(self._L.kws_model_bind_device(spec.handle))
         self._matrix = self._infer = None      # per-model precision attributes (None: library default)
+        self.weights_version = 0               # bumped whenever params / state may have changed (invalidate_prepared)
         self._ws = None
         self._ws_key = None
 
@@ -158,6 +159,10 @@ class DeviceModel(object):
         """fixed-order weight-gradient reductions (bit-identical gradients run to run; for parity tests, slow)"""
         _l.check(self._L.kws_model_set_deterministic(self.spec.handle, 1 if on else 0))
 
+    def set_overlap_point(self, point=-1):
+        """where the simple_cnn train step records overlap_event / calls overlap_callback (kws_model_set_overlap_point; scheduling only)"""
+        _l.check(self._L.kws_model_set_overlap_point(self.spec.handle, int(point)))
+
     # ---- compute ---------------------------------------------------------------------------------------------
     def new_workspace(self, batch, training=False):
         """a private workspace tensor for `batch` (InferenceSession keeps one, so that the tables prepared in it are not shared
@@ -200,6 +205,7 @@ class DeviceModel(object):
                                                      torch.cuda.current_stream().cuda_stream))
 
     def invalidate_prepared(self):
+        self.weights_version += 1
         _l.check(self._L.kws_model_invalidate_prepared(self.spec.handle))
 
     def forward(self, feat, want_probs=True, want_argmax=True, workspace=None):

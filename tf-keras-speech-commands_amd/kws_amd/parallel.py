@@ -126,6 +126,15 @@ class KwsComm(object):
         _l.check(self._L.kws_comm_allreduce(self._h, t.data_ptr(), t.numel(), dt, ro, torch.cuda.current_stream().cuda_stream))
         return t
 
+    def broadcast(self, t, src=0):
+        """kws_comm_broadcast: in-place broadcast of a contiguous CUDA tensor (any dtype: bytes travel) from rank `src`"""
+        import torch
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("kws_comm_broadcast needs a contiguous CUDA tensor")
+        _l.check(self._L.kws_comm_broadcast(self._h, t.data_ptr(), t.numel() * t.element_size(), int(src),
+                                            torch.cuda.current_stream().cuda_stream))
+        return t
+
     def timing(self, on=True):
         _l.check(self._L.kws_comm_timing(self._h, 1 if on else 0))
 
@@ -145,6 +154,39 @@ class KwsComm(object):
             self.close()
         except Exception:
             pass
+
+
+_process_comms = {}
+
+
+def process_comm(group=None):
+    """The process's communicator for `group` (None = the default group): built collectively on first use, then shared by every
+    DataParallel.for_device() -- a second ncclCommInitRank per fit() would cost ~100 ms and leave the old communicator to the garbage
+    collector.  Returns None when RCCL cannot be bound (every rank gets the same answer: the library is either loadable or not)."""
+    key = id(group) if group is not None else None
+    if key not in _process_comms:
+        try:
+            _process_comms[key] = KwsComm.from_torch_group(group)
+        except _l.KwsError as e:
+            if e.code != _l.ERR_COMM:
+                raise
+            import warnings
+            warnings.warn("RCCL is not available behind the C ABI (%s): gradients go through torch.distributed" % e)
+            _process_comms[key] = None
+    return _process_comms[key]
+
+
+def close_process_comm():
+    """Destroy the communicators process_comm() built (collective in effect: call on every rank, after the last step)."""
+    for k in list(_process_comms):
+        c = _process_comms.pop(k)
+        if c is not None:
+            c.close()
+
+
+import atexit  # noqa: E402
+
+atexit.register(close_process_comm)
 
 
 class DataParallel(object):
@@ -169,12 +211,17 @@ class DataParallel(object):
 
     @classmethod
     def for_device(cls, group=None):
-        """What `fit` uses: with an initialised multi-rank group and a GPU, an RCCL communicator behind the C ABI
-        bootstrapped over that group; else the plain torch.distributed path (or inactive)."""
+        """What `fit` uses: with an initialised multi-rank group and a GPU, THE process's RCCL communicator behind the C ABI
+        (process_comm: created once, collectively, at the first call and reused by every later fit; closed by
+        close_process_comm() or at interpreter exit, never at a garbage-collection point that differs per rank); else the plain
+        torch.distributed path (or inactive).  If RCCL cannot be bound (KWS_ERR_COMM on every rank alike: librccl missing) the
+        torch.distributed path is the fallback."""
         import torch
         d = _dist()
         if d.is_available() and d.is_initialized() and d.get_world_size(group) > 1 and torch.cuda.is_available():
-            return cls(group, comm=KwsComm.from_torch_group(group))
+            comm = process_comm(group)
+            if comm is not None:
+                return cls(group, comm=comm)
         return cls(group)
 
     @property
@@ -242,6 +289,13 @@ class DataParallel(object):
         return tensor
 
     def broadcast_(self, tensor, src=0):
+        """in place from rank `src`.  CUDA tensors with a communicator travel through the C ABI (kws_comm_broadcast), so torch never
+        builds an NCCL communicator of its own -- whose streams would change how HIP deals the step's streams to hardware queues
+        (DESIGN.md section 6)."""
+        if not self.active or self.world <= 1:
+            return tensor
+        if self.comm is not None and tensor.is_cuda:
+            return self.comm.broadcast(tensor, src)
         if self._torch_dist:
             _dist().broadcast(tensor, src, group=self.group)
         return tensor

@@ -112,10 +112,10 @@ int kws_featurize_raw_frames(const kws_featurizer *f, int32_t n_samples);
 int kws_featurize_raw(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, int32_t n_samples,
                       float *feat, void *stream);
 
-/* How much of every compute unit one launch of the tuned (default-geometry) kernel may hold: its persistent blocks take 78 KB
- * of LDS each.  2 (default): both halves of the CU's LDS, fastest when the featurizer has the chip to itself (inference,
- * dataset featurization); 1: one half, so that kernels of OTHER streams still find LDS on every CU -- use it when a batch is
- * featurized beside a running train step (kws_train_args.overlap_event): measured 0.787 -> 0.757 ms per step at B = 4096.
+/* How much of every compute unit one launch of the tuned (default-geometry) kernel may hold.  2 (default): two persistent blocks of
+ * 8 waves per CU (4 waves per SIMD, 2 x 52 KB of LDS), fastest when the featurizer has the chip to itself (inference, dataset
+ * featurization); 1: ONE block of 12 waves (75 KB of LDS), so that kernels of OTHER streams still find wave slots and LDS on every
+ * CU -- use it when a batch is featurized beside a running train step (kws_train_args.overlap_event).  Same arithmetic, same bits.
  * Other geometries (generic kernels) ignore it. */
 int kws_featurizer_set_cu_share(kws_featurizer *f, int blocks_per_cu);
 

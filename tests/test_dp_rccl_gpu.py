@@ -139,3 +139,76 @@ def test_fit_through_the_exchange_equals_plain_fit(torch, comm):
     assert hist[0] == hist[1]
     for wa, wb in zip(*weights):
         np.testing.assert_array_equal(wa, wb)
+
+
+def test_comm_broadcast_one_rank(torch, comm):
+    """kws_comm_broadcast (what fit() ships the initial weights and the epoch permutation with): byte-wise, any dtype; bad roots refused"""
+    from kws_amd import lib as L
+    for dtype in (torch.float32, torch.int64, torch.uint8):
+        t = (torch.arange(1001, device="cuda") % 251).to(dtype)
+        want = t.clone()
+        comm.broadcast(t, 0)
+        torch.cuda.synchronize()
+        assert torch.equal(t, want)
+    with pytest.raises(L.KwsError):
+        comm.broadcast(t, 1)                                 # root outside the world
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    """one process per GPU: the real N > 1 path (kws_comm over RCCL) with uneven shards incl. an empty one"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tf-keras-speech-commands_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # control plane only; the data path is kws_comm
+    from kws_amd.parallel import DataParallel, KwsComm
+    comm = KwsComm.from_torch_group()
+    dp = DataParallel(comm=comm)
+    C = 12
+    dm = _model("simple_cnn", C, 3 + rank)                  # different initial weights per rank: the broadcast must equalise them
+    dm.set_deterministic(True)
+    dp.broadcast_(dm.params)
+    dp.broadcast_(dm.state)
+    res = {}
+    for step, n_global in enumerate((96, 7, 1)):            # equal shards, uneven shards, one clip (rank 1's shard is empty)
+        x, y = _batch(n_global, C, 20 + step)
+        lo, hi, wgt = dp.shard_plan(n_global)
+        if hi > lo:
+            dm.train_fwd_bwd(torch.from_numpy(x[lo:hi]).cuda(), torch.from_numpy(y[lo:hi]).cuda(), dropout_seed=0, grad_scale=wgt, comm=comm,
+                             comm_state_weight=wgt)
+        else:
+            dm.grads.zero_()
+            comm.allreduce_grads(dm.grads, dm.grad_split, dm.state, wgt)
+        res["g%d" % step] = dm.grads.cpu().numpy().copy()
+        dm.adam_step(1e-3)
+    res["params"], res["state"] = dm.params.cpu().numpy(), dm.state.cpu().numpy()
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), **res)
+    torch.cuda.synchronize()
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl(torch, tmp_path):
+    """Needs two GPUs (the driver's multi-GPU node; skipped on a one-GPU box).  Two processes, one communicator each, uneven and empty
+    shards: every rank ends every step with identical summed gradients, and identical weights / moving statistics after Adam."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    for k in a.files:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert np.abs(a["g0"]).max() > 0 and np.abs(a["g2"]).max() > 0

@@ -574,6 +574,31 @@ def test_bucket_event_marks_final_early_gradients(torch):
         assert float(snap.abs().sum()) > 0
 
 
+def test_overlap_point_changes_scheduling_only(torch):
+    """kws_model_set_overlap_point (the tuning knob that replaced the KWS_OVERLAP_AT environment switch): wherever in the simple_cnn step
+    the overlap event / callback sits, the callback runs exactly once, the event completes, and in deterministic mode the gradients are
+    bit-identical to the default point's."""
+    from kws_amd import lib as L
+    C, B = 12, 128
+    om, dm = build("simple_cnn", C)
+    dm.set_deterministic(True)
+    x = torch.from_numpy(features(B, 8)).cuda()
+    y = torch.from_numpy(np.random.default_rng(9).integers(0, C, B).astype(np.int32)).cuda()
+    dm.train_fwd_bwd(x, y, dropout_seed=3)
+    torch.cuda.synchronize()
+    want = dm.grads.clone()
+    for point in (0, 1, 2, 3, 4, 5, 6, 7, -1):
+        dm.set_overlap_point(point)
+        calls = []
+        ev = torch.cuda.Event()
+        dm.train_fwd_bwd(x, y, dropout_seed=3, overlap_event=ev, overlap_callback=lambda: calls.append(1))
+        torch.cuda.synchronize()
+        assert calls == [1] and ev.query(), point
+        assert torch.equal(dm.grads, want), point
+    with pytest.raises(L.KwsError):
+        dm.set_overlap_point(8)
+
+
 @pytest.mark.parametrize("model_type", ["simple_cnn", "simple_cnn_lite", "simple_gru"])
 def test_overlap_and_forward_events_are_recorded_in_order(torch, model_type):
     """kws_train_args.overlap_event (simple_cnn: behind the last BatchNormalization's activation, in front of the dense layer) and

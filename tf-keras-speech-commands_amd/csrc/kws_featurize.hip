@@ -55,12 +55,13 @@ struct FeatDev {
     const int *bfirst;   // [n_filt] first non-zero bin of each band
     const int *bwidth;   // [n_filt] span length
     const float *bw;     // [n_filt][n_bins] dense bank rows (float)
-    // second-generation kernel (kws_featurize_v2.h): chunks placed on even bins, split twiddles in the kernel's lane order
-    int chp2, blocks_per_cu;
-    const int4 *chunks2; // [64 lanes] {band, first bin read (even), chunk id, 0}
-    const int *bcs2;     // [n_filt+1]
-    const float *w2;     // [64 lanes][chp2]
-    const float2 *tws2;  // [4][64]  W_1024^(ka(lane) + 64 i), ka(lane) = (lane >> 3) + 8 (lane & 7)
+    // tuned kernel (kws_featurize_v3.h): lane-linear LDS stores; chunks over POSITIONS of the two power planes, weights x 2^-12
+    int chp3, blocks_per_cu;
+    const int4 *chunks3; // [64 lanes] {band, first position read (even), chunk id, 0}
+    const int *bcs3;     // [n_filt+1]
+    const float *w3;     // [64 lanes][chp3]
+    const float2 *tw1s;  // [7][64]  W_512^(sigma(lane) A), sigma(lane) = 8 (lane & 7) + (lane >> 3)
+    const float2 *tws3;  // [4][64]  W_1024^(lane + 64 i)
 };
 
 }  // namespace kws
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(kGenWaves * 64) void featurize_generic_kernel(const
 }
 
 }  // namespace kws
-#include "kws_featurize_v2.h"
+#include "kws_featurize_v3.h"
 namespace kws {
 
 // ---------------------------------------------------------------------------------------------
@@ -607,32 +608,28 @@ static int build_bark_bank(int sample_rate, int n_fft, int n_filt, std::vector<d
 
 using namespace kws;
 
-// second-generation kernel (kws_featurize_v2.h): default frame geometry, 20 bands, 20 coefficients, no deltas
-constexpr int kV2Bands = 20, kV2Coefs = 20;
-static bool v2_applies(const FeatDev &d)
+// tuned kernel (kws_featurize_v3.h): default frame geometry, 20 bands, 20 coefficients, no deltas
+constexpr int kTunedBands = 20, kTunedCoefs = 20;
+static bool v3_applies(const FeatDev &d)
 {
-    return d.n_fft == 1024 && d.hop == 512 && d.window_eff == 1024 && !d.use_delta && d.n_filt == kV2Bands &&
-           d.n_out == kV2Coefs && (d.chp2 == 12 || d.chp2 == 16 || d.chp2 == 20);
+    return d.n_fft == 1024 && d.hop == 512 && d.window_eff == 1024 && !d.use_delta && d.n_filt == kTunedBands && d.n_out == kTunedCoefs &&
+           (d.chp3 == 12 || d.chp3 == 16 || d.chp3 == 20);
 }
-static size_t v2_smem_bytes(int chp, int waves = kV2Waves)
+static size_t v3_smem_bytes(int chp, int waves)
 {
-    constexpr int TB = 64 / kV2Bands;
-    return (size_t)waves * (kFftTile * 8 + 4 * (TB * 64 + 64 + 4)) + 4 * (size_t)(kV2Bands * kV2Coefs + 64 * chp) +
-           8 * (size_t)(7 * 64 + 7 * 8 + 4 * 64) + 4 * (size_t)round4(kV2Bands + 1);
+    constexpr int TB = 64 / kTunedBands;
+    return (size_t)waves * 4 * (kV3Tile + TB * 64 + 64 + 4) + 4 * (size_t)(kTunedBands * kTunedCoefs + 64 * chp) + 8 * (size_t)(7 * 64 + 7 * 8 + 4 * 64) +
+           4 * (size_t)round4(kTunedBands + 1);
 }
-template <typename WavT, int CHP, int WAVES = kV2Waves, bool TWREG = false>
-static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s,
-                     const char *name)
+template <typename WavT, int CHP, int WAVES>
+static int launch_v3(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s, const char *name, int bpc)
 {
-    constexpr int kV2Waves = WAVES;          // shadows the default: everything below is per configuration
-    // persistent grid: two 12-wave blocks per CU; frames per job chosen so that the jobs divide evenly over the grid's waves
     const int cus = device_cus();
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs, WAVES, TWREG>),
-                                    (int)v2_smem_bytes(CHP, WAVES)))
-        return rc;
+    const size_t smem = v3_smem_bytes(CHP, WAVES);
+    if ((size_t)WAVES * 4 * kV3Tile > 65536) return fail(KWS_ERR_UNSUPPORTED, "wave tiles must sit in the first 64 KiB of LDS (M0 holds 16 address bits)");
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(&featurize_fft1024_v3_kernel<WavT, CHP, kTunedBands, kTunedCoefs, WAVES>), (int)smem)) return rc;
     FeatDev dd = d;
-    const int bpc = d.blocks_per_cu == 1 ? 1 : 2;
-    const long waves = (long)bpc * cus * kV2Waves;
+    const long waves = (long)bpc * cus * WAVES;
     {
         // cost of a candidate = rounds of jobs per wave x (frames per job + the job's fixed part: one extra half frame of loads
         // and a partly filled tail batch); candidates: the tail batch size and up, preferring divisors of the frame count
@@ -645,28 +642,35 @@ static int launch_v2(const FeatDev &d, const WavT *wav, int B, int64_t stride, c
         }
     }
     const long jobs = (long)B * dd.jpc;
-    const unsigned grid = (unsigned)std::min<long>((long)bpc * cus, (jobs + kV2Waves - 1) / kV2Waves);
-    KWS_LAUNCH(name, (featurize_fft1024_v2_kernel<WavT, CHP, kV2Bands, kV2Coefs, WAVES, TWREG>), dim3(grid), dim3(kV2Waves * 64),
-               v2_smem_bytes(CHP, WAVES), s, wav, stride, valid_len, B, dd, feat);
-    KWS_LAUNCH_CHECK("featurize_fft1024_v2_kernel");
+    const unsigned grid = (unsigned)std::min<long>((long)bpc * cus, (jobs + WAVES - 1) / WAVES);
+    KWS_LAUNCH(name, (featurize_fft1024_v3_kernel<WavT, CHP, kTunedBands, kTunedCoefs, WAVES>), dim3(grid), dim3(WAVES * 64), smem, s, wav, stride,
+               valid_len, B, dd, feat);
+    KWS_LAUNCH_CHECK("featurize_fft1024_v3_kernel");
     return KWS_OK;
 }
-template <typename WavT>
-static int launch_v2_chp(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s,
-                         const char *name)
+#ifndef KWS_V3_ALONE_WAVES
+#define KWS_V3_ALONE_WAVES 8
+#endif
+#ifndef KWS_V3_ALONE_BLOCKS
+#define KWS_V3_ALONE_BLOCKS 2
+#endif
+template <typename WavT, int WAVES>
+static int launch_v3_chp(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s, const char *name, int bpc)
 {
-    // Sharing the chip with a train step (kws_featurizer_set_cu_share(f, 1): one 12-wave block per CU) the kernel keeps its per-lane
-    // twiddles in registers: 18 of its ~87 LDS instructions per frame go away, which the step's LDS-staged kernels beside it feel more than
-    // the featurizer itself (same-box A/B at B = 4096: step 0.674-0.684 -> 0.663-0.671 ms, the featurizer alone 0.115 -> 0.107 ms).  With
-    // the chip to itself (two blocks per CU) the 120 registers of that form allow only 16 waves per CU; measured as 2 x 8 waves it equals
-    // the LDS-twiddle form at 24 waves (featurize + forward 0.2846 vs 0.2848 ms), so the stand-alone configuration stays as it was.
-    if (d.blocks_per_cu == 1 && d.chp2 == 20) return launch_v2<WavT, 20, kV2Waves, true>(d, wav, B, stride, valid_len, feat, s, name);
-    if (d.blocks_per_cu == 1 && d.chp2 == 16) return launch_v2<WavT, 16, kV2Waves, true>(d, wav, B, stride, valid_len, feat, s, name);
-    switch (d.chp2) {
-    case 12: return launch_v2<WavT, 12>(d, wav, B, stride, valid_len, feat, s, name);
-    case 16: return launch_v2<WavT, 16>(d, wav, B, stride, valid_len, feat, s, name);
-    default: return launch_v2<WavT, 20>(d, wav, B, stride, valid_len, feat, s, name);
+    switch (d.chp3) {
+    case 12: return launch_v3<WavT, 12, WAVES>(d, wav, B, stride, valid_len, feat, s, name, bpc);
+    case 16: return launch_v3<WavT, 16, WAVES>(d, wav, B, stride, valid_len, feat, s, name, bpc);
+    default: return launch_v3<WavT, 20, WAVES>(d, wav, B, stride, valid_len, feat, s, name, bpc);
     }
+}
+// The kernel holds its per-lane twiddles in registers (110 registers: 4 waves per SIMD = 16 per CU).  With the chip to itself: two blocks of 8
+// waves per CU; beside a train step (kws_featurizer_set_cu_share(f, 1)): ONE block of 12 waves per CU, which leaves a quarter of the wave
+// slots and half of the LDS to the step's kernels.
+template <typename WavT>
+static int launch_v3_any(const FeatDev &d, const WavT *wav, int B, int64_t stride, const int32_t *valid_len, float *feat, hipStream_t s, const char *name)
+{
+    if (d.blocks_per_cu == 1) return launch_v3_chp<WavT, kV3Waves>(d, wav, B, stride, valid_len, feat, s, name, 1);
+    return launch_v3_chp<WavT, KWS_V3_ALONE_WAVES>(d, wav, B, stride, valid_len, feat, s, name, KWS_V3_ALONE_BLOCKS);
 }
 
 extern "C" {
@@ -714,27 +718,48 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
         if (a >= 0) { first[i] = a; width[i] = z - a + 1; }
     }
     // Chunk tables for the sparse band gather.  `align` = 1: a lane reads its bins one per LDS instruction (first-generation
-    // kernel); 2: chunks start on even bins so that two bins come per ds_read_b64 (kws_featurize_v2.h).
+    // kernel); 2: chunks start on even positions so that two bins come per ds_read_b64 (kws_featurize_v3.h).
     struct ChunkTables { int ch, chp, nlog; std::vector<int4> chunks; std::vector<float> w; std::vector<int> bcs; };
-    auto build_chunks = [&](int align) {
+    // `mirrored` (third-generation kernel): the chunks run over POSITIONS of the wave's two power planes (v3_pos_of_bin: bins 0..256 in
+    // place, bins 257..512 in descending order behind them), a band's span splits into at most two runs of consecutive positions, and the
+    // weights carry the factor 2^-12 the kernel leaves out of its power spectrum
+    auto build_chunks = [&](int align, bool mirrored = false) {
         ChunkTables T;
+        const int npos = mirrored ? kV3OffM + 256 : n_bins;
+        std::vector<int> bin_of(npos, -1);
+        for (int k = 0; k < n_bins; ++k) bin_of[mirrored ? v3_pos_of_bin(k) : k] = k;
+        const double wscale = mirrored ? 1.0 / 4096.0 : 1.0;
+        struct Run { int band, lo, hi; };                        // positions [lo, hi)
+        std::vector<Run> runs;
+        for (int i = 0; i < n_filt; ++i) {
+            if (width[i] <= 0) continue;
+            if (!mirrored) { runs.push_back(Run{i, first[i], first[i] + width[i]}); continue; }
+            const int a = first[i], z = first[i] + width[i] - 1;
+            if (a <= 256) runs.push_back(Run{i, a, std::min(z, 256) + 1});
+            if (z >= 257) runs.push_back(Run{i, v3_pos_of_bin(z), v3_pos_of_bin(std::max(a, 257)) + 1});
+        }
         int ch = align;
         for (;; ch += align) {
             int cnt = 0;
-            for (int i = 0; i < n_filt; ++i) cnt += (width[i] + (first[i] % align) + ch - 1) / ch;
+            for (const Run &r : runs) cnt += ((r.hi - r.lo) + (r.lo % align) + ch - 1) / ch;
             if (cnt <= kMaxChunks) break;
         }
         const int chp = (ch + 3) & ~3;
-        // logical chunks in band order: (band, first bin, bins); chunk boundaries sit on multiples of `align`
+        // logical chunks in band order: (band, first position, positions); chunk boundaries sit on multiples of `align`
         struct Chunk { int band, a, len; };
         std::vector<Chunk> logical;
         std::vector<int> bcs(n_filt + 1, 0);
-        for (int i = 0; i < n_filt; ++i) {
-            bcs[i] = (int)logical.size();
-            const int s0 = first[i] - first[i] % align, end = first[i] + width[i];
-            for (int lo = s0; lo < end; lo += ch) {
-                const int a = std::max(lo, first[i]), z = std::min(lo + ch, end);
-                if (z > a) logical.push_back(Chunk{i, a, z - a});
+        {
+            size_t ri = 0;
+            for (int i = 0; i < n_filt; ++i) {
+                bcs[i] = (int)logical.size();
+                for (; ri < runs.size() && runs[ri].band == i; ++ri) {
+                    const int s0 = runs[ri].lo - runs[ri].lo % align, end = runs[ri].hi;
+                    for (int lo = s0; lo < end; lo += ch) {
+                        const int a = std::max(lo, runs[ri].lo), z = std::min(lo + ch, end);
+                        if (z > a) logical.push_back(Chunk{i, a, z - a});
+                    }
+                }
             }
         }
         bcs[n_filt] = (int)logical.size();
@@ -784,15 +809,17 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
             if (c < 0) { T.chunks[lane] = make_int4(0, 0, spare < 64 ? spare++ : 63, 0); continue; }
             T.chunks[lane] = make_int4(logical[c].band, start_of[c], c, 0);
             for (int t = 0; t < chp; ++t) {
-                const int bin = start_of[c] + t;
-                if (bin >= logical[c].a && bin < logical[c].a + logical[c].len)
-                    T.w[(size_t)lane * chp + t] = (float)bank[(size_t)logical[c].band * n_bins + bin];
+                const int pos = start_of[c] + t;
+                if (pos >= logical[c].a && pos < logical[c].a + logical[c].len && pos < npos && bin_of[pos] >= 0)
+                    T.w[(size_t)lane * chp + t] = (float)((double)(float)bank[(size_t)logical[c].band * n_bins + bin_of[pos]] * wscale);
             }
         }
         T.ch = ch; T.chp = chp; T.nlog = nlog; T.bcs = bcs;
         return T;
     };
-    const ChunkTables T1 = build_chunks(1), T2 = build_chunks(2);
+    const ChunkTables T1 = build_chunks(1);
+    const bool v3_geom = p->n_fft == 1024;                                   // the position map is the 513-bin one
+    const ChunkTables T3 = build_chunks(2, v3_geom);
     const int chp = T1.chp, nlog = T1.nlog, n_filt_pad = (n_filt + 3) & ~3;
     const std::vector<int4> &chunks = T1.chunks;
     const std::vector<float> &w = T1.w;
@@ -813,11 +840,16 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
         const double a = -2.0 * M_PI * (double)k / 1024.0;
         tws[k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
-    std::vector<float2> tws2(4 * 64);
+    std::vector<float2> tw1s(7 * 64), tws3(4 * 64);
+    for (int k = 1; k < 8; ++k)
+        for (int l = 0; l < 64; ++l) {
+            const double a = -2.0 * M_PI * (double)(v3_sigma(l) * k) / 512.0;
+            tw1s[(k - 1) * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
     for (int i = 0; i < 4; ++i)
         for (int l = 0; l < 64; ++l) {
-            const double a = -2.0 * M_PI * (double)(v2_ka(l) + 64 * i) / 1024.0;
-            tws2[i * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
+            const double a = -2.0 * M_PI * (double)(l + 64 * i) / 1024.0;
+            tws3[i * 64 + l] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
     // generic-path tables (used when n_fft != 1024)
     std::vector<float2> twg((size_t)p->n_fft / 2);
@@ -848,8 +880,9 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
                  o_ch = al(o_tws + tws.size() * 8), o_bcs = al(o_ch + std::max<size_t>(1, chunks.size()) * 16),
                  o_w = al(o_bcs + bcs.size() * 4), o_dct = al(o_w + std::max<size_t>(1, w.size()) * 4),
                  o_twg = al(o_dct + dct.size() * 4), o_bf = al(o_twg + twg.size() * 8), o_bwd = al(o_bf + first.size() * 4),
-                 o_bw = al(o_bwd + width.size() * 4), o_ch2 = al(o_bw + bwf.size() * 4), o_bcs2 = al(o_ch2 + 64 * 16),
-                 o_w2 = al(o_bcs2 + T2.bcs.size() * 4), o_tws2 = al(o_w2 + T2.w.size() * 4), total = al(o_tws2 + tws2.size() * 8);
+                 o_bw = al(o_bwd + width.size() * 4), o_ch3 = al(o_bw + bwf.size() * 4),
+                 o_bcs3 = al(o_ch3 + 64 * 16), o_w3 = al(o_bcs3 + T3.bcs.size() * 4), o_tw1s = al(o_w3 + T3.w.size() * 4),
+                 o_tws3 = al(o_tw1s + tw1s.size() * 8), total = al(o_tws3 + tws3.size() * 8);
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + o_tw1, tw1.data(), tw1.size() * 8);
     std::memcpy(host.data() + o_tw2, tw2.data(), tw2.size() * 8);
@@ -862,10 +895,11 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     std::memcpy(host.data() + o_bf, first.data(), first.size() * 4);
     std::memcpy(host.data() + o_bwd, width.data(), width.size() * 4);
     std::memcpy(host.data() + o_bw, bwf.data(), bwf.size() * 4);
-    std::memcpy(host.data() + o_ch2, T2.chunks.data(), 64 * 16);
-    std::memcpy(host.data() + o_bcs2, T2.bcs.data(), T2.bcs.size() * 4);
-    std::memcpy(host.data() + o_w2, T2.w.data(), T2.w.size() * 4);
-    std::memcpy(host.data() + o_tws2, tws2.data(), tws2.size() * 8);
+    std::memcpy(host.data() + o_ch3, T3.chunks.data(), 64 * 16);
+    std::memcpy(host.data() + o_bcs3, T3.bcs.data(), T3.bcs.size() * 4);
+    std::memcpy(host.data() + o_w3, T3.w.data(), T3.w.size() * 4);
+    std::memcpy(host.data() + o_tw1s, tw1s.data(), tw1s.size() * 8);
+    std::memcpy(host.data() + o_tws3, tws3.data(), tws3.size() * 8);
     hipError_t e = hipMalloc(&f->dmem, total);
     if (e == hipSuccess) e = hipMemcpy(f->dmem, host.data(), total, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -895,11 +929,12 @@ int kws_featurizer_create(const kws_params *p, int bank_kind, kws_featurizer **o
     d.bfirst = reinterpret_cast<const int *>(base + o_bf);
     d.bwidth = reinterpret_cast<const int *>(base + o_bwd);
     d.bw = reinterpret_cast<const float *>(base + o_bw);
-    d.chp2 = T2.nlog <= 64 ? T2.chp : 0;
-    d.chunks2 = reinterpret_cast<const int4 *>(base + o_ch2);
-    d.bcs2 = reinterpret_cast<const int *>(base + o_bcs2);
-    d.w2 = reinterpret_cast<const float *>(base + o_w2);
-    d.tws2 = reinterpret_cast<const float2 *>(base + o_tws2);
+    d.chp3 = (v3_geom && T3.nlog <= 64) ? T3.chp : 0;
+    d.chunks3 = reinterpret_cast<const int4 *>(base + o_ch3);
+    d.bcs3 = reinterpret_cast<const int *>(base + o_bcs3);
+    d.w3 = reinterpret_cast<const float *>(base + o_w3);
+    d.tw1s = reinterpret_cast<const float2 *>(base + o_tw1s);
+    d.tws3 = reinterpret_cast<const float2 *>(base + o_tws3);
     // the LDS the launch will ask for (same job shape as launch_featurize / launch_generic, same 160 KiB limit)
     if (d.n_fft == 1024) {
         feat_job_shape(d);
@@ -971,11 +1006,11 @@ static int launch_featurize(const FeatDev &d0, const void *wav, int wav_dtype, i
     if (d0.n_fft != 1024) return launch_generic(d0, wav, wav_dtype, B, stride, valid_len, feat, stream);
     FeatDev d = d0;
     feat_job_shape(d);
-    if (v2_applies(d)) {
+    if (v3_applies(d)) {
         if (wav_dtype == KWS_WAV_F32)
-            return launch_v2_chp(d, static_cast<const float *>(wav), B, stride, valid_len, feat, static_cast<hipStream_t>(stream), "featurize_fft1024_f32");
+            return launch_v3_any(d, static_cast<const float *>(wav), B, stride, valid_len, feat, static_cast<hipStream_t>(stream), "featurize_fft1024_f32");
         if (wav_dtype == KWS_WAV_I16)
-            return launch_v2_chp(d, static_cast<const short *>(wav), B, stride, valid_len, feat, static_cast<hipStream_t>(stream), "featurize_fft1024_i16");
+            return launch_v3_any(d, static_cast<const short *>(wav), B, stride, valid_len, feat, static_cast<hipStream_t>(stream), "featurize_fft1024_i16");
         return fail(KWS_ERR_INVALID, "unknown wav dtype %d", wav_dtype);
     }
     const size_t smem = feat_smem_bytes(d);

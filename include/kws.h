@@ -101,6 +101,11 @@ int kws_featurizer_bank(const kws_featurizer *f, float *host_bank, size_t count)
  */
 int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride,
                   const int32_t *valid_len, float *feat, void *stream);
+/* The same for B clips GATHERED from a device-resident dataset: clip b is row index[b] (device int32) of `wav` (rows x stride) and of
+ * `valid_len` (one length per ROW).  This is the minibatch draw of model.fit(shuffle=True) (train.py:81-92) without a copy of the
+ * audio: the reference's fit gathers feature rows on the host; here a step's 4096 x 64 KB of samples are read in place. */
+int kws_featurize_gather(kws_featurizer *f, const void *wav, int wav_dtype, const int32_t *index, int B, int64_t stride,
+                         const int32_t *valid_len, float *feat, void *stream);
 
 /*
  * vectorize_raw (common/data_utils.py:61-70): audio of exactly n_samples per clip, no length

@@ -292,6 +292,70 @@ def test_sessions_of_two_precisions_share_a_model(torch):
     assert float((a16 - a32).abs().max()) < 2e-3
 
 
+@pytest.mark.parametrize("model_type,audio", [("simple_cnn", True), ("simple_cnn", False), ("simple_cnn_lite", True), ("simple_gru", False)])
+def test_fit_pipelined_equals_stepwise(torch, model_type, audio):
+    """KWSModel.fit runs the pipelined step bench.py measures (next batch drawn / featurized in place on a side stream from the step's
+    overlap point, labels gathered there too, layer-1 moments from the pipeline, per-step statistics rows); `pipeline=False` is the same
+    arithmetic on one stream.  Shuffled epochs with a partial last batch: identical history and, in the deterministic gradient mode,
+    bit-identical weights (the recurrent model has no such mode: 1e-5)."""
+    from classifier.loss import SparseCategoricalCrossEntropy
+    from classifier.model import KWSModel
+    from common.model_utils import get_optimizer
+    C, N = 4, 150
+    rng = np.random.default_rng(5)
+    y = rng.integers(0, C, N)
+    if audio:
+        tones = np.sin(2 * np.pi * (300.0 * (1 + np.arange(C)))[:, None] * np.arange(16000)[None, :] / 16000.0)
+        x = (0.3 * tones[y] + 0.05 * rng.standard_normal((N, 16000))).astype(np.float32)
+    else:
+        protos = rng.standard_normal((C, 30, 20)) * 2
+        x = (protos[y] + 0.5 * rng.standard_normal((N, 30, 20))).astype(np.float32)
+        if model_type != "simple_gru":
+            x = x[..., None]
+    det = model_type != "simple_gru"
+    hist, weights = [], []
+    for pipelined in (False, True):
+        torch.manual_seed(1234)
+        m = KWSModel(model_type, C, seed=3)
+        if det:
+            m._device().set_deterministic(True)
+        m.compile(optimizer=get_optimizer("adam", 1e-3), loss=SparseCategoricalCrossEntropy(), metrics=["accuracy"])
+        h = m.fit(x, y, batch_size=64, epochs=3, verbose=0, shuffle=True, pipeline=pipelined)
+        hist.append((h.history["loss"], h.history["accuracy"]))
+        weights.append(m.get_weights())
+        assert h.history["clips_per_sec"][-1] > 0
+    if det:
+        assert hist[0] == hist[1]
+        for wa, wb in zip(*weights):
+            np.testing.assert_array_equal(wa, wb)
+    else:
+        np.testing.assert_allclose(hist[0][0], hist[1][0], rtol=1e-5)
+        for wa, wb in zip(*weights):
+            np.testing.assert_allclose(wa, wb, rtol=0, atol=1e-5)
+    assert hist[1][0][-1] < hist[1][0][0]                   # and it trains
+
+
+def test_featurize_gather_equals_featurizing_a_copy(torch):
+    """kws_featurize_gather: clip b = row index[b] of the dataset (and of valid_len), for the tuned and the generic kernels, float32 and PCM16"""
+    from classifier.params import ListenerParams, pr
+    from kws_amd.featurizer import Featurizer
+    rng = np.random.default_rng(3)
+    rows, B = 97, 41
+    a = np.clip(0.2 * rng.standard_normal((rows, 16000)), -1, 1 - 2.0 ** -15).astype(np.float32)
+    lens = rng.integers(3000, 16001, rows).astype(np.int32)
+    idx = rng.integers(0, rows, B).astype(np.int32)
+    wav, vl, ix = torch.from_numpy(a).cuda(), torch.from_numpy(lens).cuda(), torch.from_numpy(idx).cuda()
+    w16 = torch.from_numpy((a * 32768).astype(np.int16)).cuda()
+    p512 = ListenerParams(1.0, 0.032, 0.016, 16000, 2, 512, 20, 13, False, ((6, 4),), 0.2)
+    for params in (pr, p512):
+        f = Featurizer(params)
+        for src in (wav, w16):
+            want = f(src.index_select(0, ix.long()).contiguous(), vl.index_select(0, ix.long()).contiguous())
+            got = f(src, vl, index=ix)
+            assert torch.equal(got, want)
+            assert torch.equal(f(src, index=ix), f(src.index_select(0, ix.long()).contiguous()))
+
+
 def test_eight_example_clips_argmax_agreement(torch, golden):
     """SURVEY 8(d) substitute for the unavailable Speech Commands v2 top-1: train on a synthetic separable task through the host
     API, then run the reference's eight example clips (example/*.wav, PCM in the golden file) through featurize + predict on

@@ -265,12 +265,21 @@ class KWSModel(object):
         """Keras-style training loop (train.py:81-92).  The dataset is placed in HBM once; every epoch draws a fresh
         permutation on the device, the partial last batch is kept, per-epoch loss/accuracy are the sample-weighted
         means of the batches.  Under torch.distributed each rank trains on its slice of every global batch and the
-        gradients / BatchNormalization statistics are exchanged through the C ABI (kws_amd.parallel, csrc/kws_comm.hip)."""
+        gradients / BatchNormalization statistics are exchanged through the C ABI (kws_amd.parallel, csrc/kws_comm.hip).
+
+        The step that runs is the pipelined one bench.py measures (kws_amd.pipeline.FeaturePipeline): while batch k trains, batch k+1 is
+        drawn from the resident dataset on a side stream -- raw audio is featurized IN PLACE from the rows the permutation names
+        (kws_featurize_gather), features are gathered -- together with its labels and, for simple_cnn, the second moments of its features
+        (kws_train_args.feat_moments); the side stream starts at the step's overlap point (overlap_event / overlap_callback).  Nothing
+        on the host waits for the device inside an epoch.  `pipeline=False` runs the same arithmetic step by step on one stream
+        (bit-identical results in the deterministic gradient mode: tests/test_host_api_gpu.py)."""
         import torch
         from kws_amd.parallel import DataParallel
+        from kws_amd.pipeline import FeaturePipeline
         dm = self._device()
         cw, ig = self._loss_args()
         dp = kwargs.pop("data_parallel", None) or DataParallel.for_device()    # injectable for tests (a forced one-rank world)
+        pipelined = bool(kwargs.pop("pipeline", True))
         if dp.active:
             dp.broadcast_(dm.params)
             dp.broadcast_(dm.state)
@@ -288,6 +297,21 @@ class KWSModel(object):
         self.stop_training = False
         steps = max(1, math.ceil(n / batch_size))
         self._global_step = getattr(self, "_global_step", 0)
+        nf, fs = pr.n_features, pr.feature_size
+        local_max = dp.shard(batch_size)[1] - dp.shard(batch_size)[0] if dp.active else batch_size
+        pipe = None
+        if pipelined:
+            key = (local_max, is_audio, nf, fs)
+            if getattr(self, "_pipe_key", None) != key:
+                from kws_amd.featurizer import Featurizer
+                # its own featurizer object: beside a train step it runs in the one-block-per-CU configuration (same bits)
+                self._pipe = FeaturePipeline(Featurizer(pr) if is_audio else None, max(1, local_max), nf, fs, device=xd.device,
+                                             moments=self.model_type == 'simple_cnn', labels=True)
+                self._pipe_key = key
+            pipe = self._pipe
+        stats_all = torch.zeros((steps, 2), dtype=torch.float32, device=xd.device)     # one row per step: no per-step accumulation kernels
+        overlap_ev = torch.cuda.Event()
+        state = dm.state if self.spec.state_count > 0 else None
         for epoch in range(initial_epoch, epochs):
             for cb in callbacks:
                 cb.on_epoch_begin(epoch)
@@ -298,29 +322,76 @@ class KWSModel(object):
                     dp.broadcast_(perm)
             else:
                 perm = torch.arange(n, device=xd.device)
-            acc = torch.zeros((2,), dtype=torch.float64, device=xd.device)
+            perm = perm.to(torch.int32)
+            stats_all.zero_()
             seen = 0
-            for i in range(steps):
+
+            def shard_of(i):
                 idx = perm[i * batch_size:(i + 1) * batch_size]
-                weight = None
                 if dp.active:
                     lo, hi, weight = dp.shard_plan(idx.numel())     # an empty shard (weight 0) still joins the collectives
-                    idx = idx[lo:hi]
+                    return idx[lo:hi], weight
+                return idx, None
+
+            def submit(i, after=None):
+                idx, _ = shard_of(i)
+                if idx.numel() > 0:
+                    if is_audio:
+                        pipe.submit(wav=xd, index=idx, labels=yd, after=after)
+                    else:
+                        pipe.submit(features=xd, index=idx, labels=yd, after=after)
+
+            if pipe is not None:
+                submit(0)
+            for i in range(steps):
+                idx, weight = shard_of(i)
+                nloc = idx.numel()
                 self._global_step += 1
                 seed = (self._dropout_base << 20) + self._global_step * 64 + dp.rank
-                st = self._train_batch(dm, dp, xd.index_select(0, idx), yd.index_select(0, idx), is_audio, cw, ig, seed, weight)
-                acc += st.double()
-                seen += idx.numel()
-            tot = torch.cat([acc, torch.tensor([float(seen)], dtype=torch.float64, device=xd.device)])
+                more = pipe is not None and i + 1 < steps
+                if nloc > 0:
+                    mom = None
+                    if pipe is not None:
+                        got = pipe.take()
+                        feat, yb = got[0], got[-1]
+                        mom = got[1] if len(got) == 3 else None
+                    else:
+                        xb = xd.index_select(0, idx)
+                        feat, yb = self._features_of(xb, is_audio), yd.index_select(0, idx)
+                    kw = dict(dropout_seed=seed, ignore_index=ig, feat_moments=mom, stats_out=stats_all[i])
+                    if more:
+                        kw.update(overlap_event=overlap_ev, overlap_callback=lambda j=i + 1: submit(j, after=overlap_ev))
+                    if dp.active:
+                        w = dp.grad_scale if weight is None else weight
+                        if dp.comm is not None:
+                            dm.train_fwd_bwd(feat, yb, cw, grad_scale=w, comm=dp.comm, comm_state_weight=w, **kw)
+                        else:
+                            dm.train_fwd_bwd(feat, yb, cw, grad_scale=w, bucket_event=self._bucket_event, **kw)
+                            dp.sync_grads(dm.grads, dm.grad_split, self._bucket_event, state=state, state_weight=w)
+                    else:
+                        dm.train_fwd_bwd(feat, yb, cw, **kw)
+                else:
+                    # this rank's shard of a partial batch is empty: cleared gradients, weight 0, the same collectives
+                    dm.grads.zero_()
+                    if dp.comm is not None:
+                        dp.comm.allreduce_grads(dm.grads, dm.grad_split, state, weight)
+                    else:
+                        self._bucket_event.record()
+                        dp.sync_grads(dm.grads, dm.grad_split, self._bucket_event, state=state, state_weight=weight)
+                    if more:
+                        submit(i + 1)
+                self._apply_optimizer(dm)
+                seen += nloc
+            tot = torch.cat([stats_all.double().sum(0), torch.tensor([float(seen)], dtype=torch.float64, device=xd.device)])
             if dp.active:
                 dp.sum_(tot)                     # (the BatchNormalization moving statistics are averaged every step)
             tot = tot.cpu().numpy()
+            dt = time.time() - t0                # the device is idle again here (tot.cpu() waited for the last step)
             logs = {'loss': float(tot[0] / tot[2]), 'accuracy': float(tot[1] / tot[2])}
             if validation_data is not None and (epoch + 1) % validation_freq == 0:
                 vl, va = self.evaluate(validation_data[0], validation_data[1], batch_size=batch_size, verbose=0)
                 logs['val_loss'], logs['val_accuracy'] = vl, va
             logs['lr'] = self.optimizer.current_lr()
-            dt = time.time() - t0
             logs['clips_per_sec'] = float(tot[2] / dt) if dt > 0 else 0.0
             if verbose and dp.rank == 0:
                 print('Epoch %d/%d - %.1fs - %s' % (epoch + 1, epochs, dt, ' - '.join(

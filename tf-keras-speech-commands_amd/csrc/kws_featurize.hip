@@ -41,6 +41,7 @@ struct FeatDev {
     int chp, n_filt_pad;   // chunk length padded to a multiple of 4 (zero weights); n_filt rounded up to 4 (zero DCT rows)
     int tail_batch;        // frames whose band sums / DCT one wave evaluates together (lanes = frames x bands)
     int fpw, jpc;          // frames per wave job, jobs per clip (set per launch: launch_featurize)
+    const int32_t *index;  // NULL, or B device ints: clip b is ROW index[b] of wav / valid_len (kws_featurize_gather; set per launch)
     float inv_nfft;
     const float2 *tw1;   // [7][64]  W_512^(lane*k1), k1 = 1..7
     const float2 *tw2;   // [7][8]   W_64^(l2*k2a),   k2a = 1..7
@@ -208,12 +209,13 @@ __global__ __launch_bounds__(kThreads, 5) void featurize_fft1024_kernel(const Wa
 
     // clip geometry: keep the head, left-pad zeros (data_utils.py:77-80)
     const int bc = b < B ? b : 0;                                          // idle waves (no job) read clip 0's geometry and do nothing
-    int len = valid_len ? valid_len[bc] : (stride > c.max_samples ? c.max_samples : (int)stride);
+    const int row = c.index ? c.index[bc] : bc;
+    int len = valid_len ? valid_len[row] : (stride > c.max_samples ? c.max_samples : (int)stride);
     len = len < 0 ? 0 : len;
     if ((int64_t)len > stride) len = (int)stride;
     if (len > c.max_samples) len = c.max_samples;
     const int pad = c.max_samples - len;
-    const WavT *src = wav + (int64_t)bc * stride;
+    const WavT *src = wav + (int64_t)row * stride;
     const bool vec_ok = (((pad | c.hop | c.window_eff) & 1) == 0) &&
                         ((reinterpret_cast<uintptr_t>(src) & (2 * sizeof(WavT) - 1)) == 0);
     const bool reuse = 2 * c.hop == 1024 && c.window_eff == 1024;          // frame f+1 starts with frame f's upper half
@@ -434,12 +436,13 @@ __global__ __launch_bounds__(kGenWaves * 64) void featurize_generic_kernel(const
     float *s_mel = reinterpret_cast<float *>(smem + (size_t)kGenWaves * N * 8) + wave * 64;
     float *s_feat = reinterpret_cast<float *>(smem + (size_t)kGenWaves * N * 8 + kGenWaves * 256);
 
-    int len = valid_len ? valid_len[b] : (stride > c.max_samples ? c.max_samples : (int)stride);
+    const int row = c.index ? c.index[b] : b;
+    int len = valid_len ? valid_len[row] : (stride > c.max_samples ? c.max_samples : (int)stride);
     len = len < 0 ? 0 : len;
     if ((int64_t)len > stride) len = (int)stride;
     if (len > c.max_samples) len = c.max_samples;
     const int pad = c.max_samples - len;
-    const WavT *src = wav + (int64_t)b * stride;
+    const WavT *src = wav + (int64_t)row * stride;
 
     for (int f = wave; f < c.n_frames; f += kGenWaves) {
         const int base = f * c.hop;
@@ -1037,8 +1040,8 @@ static int launch_featurize(const FeatDev &d0, const void *wav, int wav_dtype, i
     return KWS_OK;
 }
 
-int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, const int32_t *valid_len,
-                  float *feat, void *stream)
+int kws_featurize_gather(kws_featurizer *f, const void *wav, int wav_dtype, const int32_t *index, int B, int64_t stride,
+                         const int32_t *valid_len, float *feat, void *stream)
 {
     if (!f || !feat || (!wav && B > 0)) return fail(KWS_ERR_INVALID, "null argument");
     if (B < 0 || stride < 0) return fail(KWS_ERR_INVALID, "negative batch or stride");
@@ -1046,7 +1049,14 @@ int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int6
     if (!valid_len && stride < 1) return fail(KWS_ERR_INVALID, "stride must be >= 1 when valid_len is NULL");
     FeatDev d = f->dev;
     d.blocks_per_cu = f->blocks_per_cu;
+    d.index = index;
     return launch_featurize(d, wav, wav_dtype, B, stride, valid_len, feat, stream);
+}
+
+int kws_featurize(kws_featurizer *f, const void *wav, int wav_dtype, int B, int64_t stride, const int32_t *valid_len,
+                  float *feat, void *stream)
+{
+    return kws_featurize_gather(f, wav, wav_dtype, nullptr, B, stride, valid_len, feat, stream);
 }
 
 int kws_featurizer_set_cu_share(kws_featurizer *f, int blocks_per_cu)

@@ -284,12 +284,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void featurize_fft1024_v3_kernel(con
     const int b = job / c.jpc;
     // clip geometry: keep the head, left-pad zeros (data_utils.py:77-80)
     const int bc = b;
-    int len = valid_len ? valid_len[bc] : (stride > c.max_samples ? c.max_samples : (int)stride);
+    const int row = c.index ? c.index[bc] : bc;                            // kws_featurize_gather: clip bc is a row of the caller's dataset
+    int len = valid_len ? valid_len[row] : (stride > c.max_samples ? c.max_samples : (int)stride);
     len = len < 0 ? 0 : len;
     if ((int64_t)len > stride) len = (int)stride;
     if (len > c.max_samples) len = c.max_samples;
     const int pad = c.max_samples - len;
-    const WavT *src = wav + (int64_t)bc * stride;
+    const WavT *src = wav + (int64_t)row * stride;
     const bool vec_ok = ((pad & 1) == 0) && ((reinterpret_cast<uintptr_t>(src) & (2 * sizeof(WavT) - 1)) == 0);
 
     float *dst = feat + (int64_t)bc * c.n_frames * NO;

@@ -81,22 +81,31 @@ class Featurizer(object):
             return _l.WAV_I16
         raise TypeError("waveforms must be float32 or int16, got %s" % t.dtype)
 
-    def __call__(self, wav, valid_len=None, out=None):
-        """wav: CUDA tensor (B, stride) float32|int16; valid_len: optional CUDA int32 (B,)."""
+    def __call__(self, wav, valid_len=None, out=None, index=None):
+        """wav: CUDA tensor (rows, stride) float32|int16; valid_len: optional CUDA int32 (rows,).  index: optional CUDA int32 (B,): featurize
+        the B rows wav[index[b]] in place of all rows (kws_featurize_gather: a shuffled minibatch of a device-resident dataset, no copy)."""
         torch = _torch()
         if not wav.is_cuda or wav.dim() != 2 or not wav.is_contiguous():
             raise ValueError("wav must be a contiguous CUDA tensor of shape (B, stride)")
-        B, stride = wav.shape
+        rows, stride = wav.shape
+        B = rows
+        ix = 0
+        if index is not None:
+            if index.dtype != torch.int32 or not index.is_cuda or index.dim() != 1 or not index.is_contiguous():
+                raise ValueError("index must be a contiguous CUDA int32 vector")
+            B, ix = index.numel(), index.data_ptr()
         g = self.geometry
         if out is None:
             out = torch.empty((B, g["n_features"], g["feature_size"]), dtype=torch.float32, device=wav.device)
+        elif out.numel() < B * g["n_features"] * g["feature_size"] or not out.is_contiguous():
+            raise ValueError("out is too small for %d clips" % B)
         vl = 0
         if valid_len is not None:
-            if valid_len.dtype != torch.int32 or not valid_len.is_cuda or valid_len.numel() != B:
-                raise ValueError("valid_len must be a CUDA int32 tensor with B elements")
+            if valid_len.dtype != torch.int32 or not valid_len.is_cuda or valid_len.numel() != rows:
+                raise ValueError("valid_len must be a CUDA int32 tensor with one element per row of wav")
             vl = valid_len.data_ptr()
-        _l.check(self._L.kws_featurize(self._h, wav.data_ptr(), self._dtype_code(wav), B, stride, vl, out.data_ptr(),
-                                       torch.cuda.current_stream().cuda_stream))
+        _l.check(self._L.kws_featurize_gather(self._h, wav.data_ptr(), self._dtype_code(wav), ix, B, stride, vl, out.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
         return out
 
     def raw(self, wav, n_samples=None):

@@ -78,6 +78,7 @@ def get_lib():
     L.kws_featurizer_geometry.argtypes = [vp, ctypes.POINTER(KwsGeometry)]
     L.kws_featurizer_bank.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t]
     L.kws_featurize.argtypes = [vp, vp, i32, i32, i64, vp, fp, vp]
+    L.kws_featurize_gather.argtypes = [vp, vp, i32, vp, i32, i64, vp, fp, vp]
     L.kws_featurizer_set_cu_share.argtypes = [vp, i32]
     L.kws_featurize_raw.argtypes = [vp, vp, i32, i32, i64, i32, fp, vp]
     u64, f32 = ctypes.c_uint64, ctypes.c_float

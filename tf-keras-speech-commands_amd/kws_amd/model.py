@@ -221,13 +221,14 @@ class DeviceModel(object):
 
     def train_fwd_bwd(self, feat, labels, class_weights=None, dropout_seed=0, grad_scale=1.0, want_probs=False,
                       ignore_index=0, bucket_event=None, forward_event=None, overlap_event=None, overlap_callback=None,
-                      feat_moments=None, comm=None, comm_state_weight=1.0):
+                      feat_moments=None, comm=None, comm_state_weight=1.0, stats_out=None):
         """labels: CUDA int32 (B,); class_weights: CUDA float32 (C,) or None.  Leaves grads in self.grads and
         {sum of losses, top-1 hits} in self.stats (device).  bucket_event: torch.cuda.Event recorded when the early
         gradient bucket [grad_split, P) is final.  feat_moments: the float64 CUDA tensor feature_moments(feat) returned (optional;
         simple_cnn then skips its own moment pass at the head of the step).  comm: a kws_amd.parallel.KwsComm -- the step then sums its
         gradients (and the BatchNormalization statistics times comm_state_weight) over the ranks itself, the early bucket under
-        the rest of the backward pass; pass grad_scale = comm_state_weight = local clips / global clips."""
+        the rest of the backward pass; pass grad_scale = comm_state_weight = local clips / global clips.  stats_out: 2 contiguous CUDA
+        floats that receive {sum of losses, hits} instead of self.stats (a fit loop gives every step its own row and sums once per epoch)."""
         torch = _torch()
         B = self._check_feat(feat)
         if labels.dtype != torch.int32 or not labels.is_cuda or labels.numel() != B:
@@ -242,7 +243,9 @@ class DeviceModel(object):
         a.ws, a.ws_bytes = ws, nbytes
         a.dropout_seed, a.grad_scale = int(dropout_seed) & 0xFFFFFFFFFFFFFFFF, float(grad_scale)
         a.probs = probs.data_ptr() if want_probs else None
-        a.stats = self.stats.data_ptr()
+        if stats_out is not None and (stats_out.dtype != torch.float32 or not stats_out.is_cuda or stats_out.numel() != 2 or not stats_out.is_contiguous()):
+            raise ValueError("stats_out must be 2 contiguous CUDA float32 values")
+        a.stats = (self.stats if stats_out is None else stats_out).data_ptr()
         if comm is not None:
             a.comm = comm.handle
             a.comm_state_weight = float(comm_state_weight)

@@ -43,8 +43,53 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak
 N_CLASSES = 36
 FWD_BYTES_PER_CLIP = 64144.0   # 64 000 B waveform in + 36 x 4 B probabilities out (features stay on chip)
 FEAT_BYTES_PER_CLIP = 66400.0  # featurizer alone, 64 000 in + 2 400 out
-TRAFFIC_RECORD = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-PMC_RECORD = os.path.join(ROOT, "profiles", "r02_pmc_dense_head.json")
+PMC_RECORD = os.path.join(ROOT, "profiles", "r03_pmc.json")     # tools/r03_records.py: counters + pipe floors per workload and kernel
+# the source files a workload's kernels live in: a record measured on other sources of THESE files is stale and not quoted
+PMC_SOURCES = {"feat": ("kws_featurize.hip", "kws_featurize_v3.h"), "feat_shared": ("kws_featurize.hip", "kws_featurize_v3.h"),
+               "gru": ("kws_rnn.hip", "kws_gru.h"), "lstm": ("kws_rnn.hip", "kws_lstm.h"),
+               "lite16": ("kws_lite.h", "kws_lite_f16.h", "kws_featurize.hip", "kws_featurize_v3.h"),
+               "infer": ("kws_model.hip", "kws_conv.h", "kws_layers.h", "kws_layer1.h", "kws_infer_fused.h", "kws_featurize.hip", "kws_featurize_v3.h"),
+               "step": ("kws_model.hip", "kws_conv.h", "kws_layers.h", "kws_layer1.h", "kws_layer1_fast.h", "kws_layer1_moments.h")}
+_pmc_cache = {}
+
+
+def pmc_record(workload, kernel, build_id):
+    """-> (derived figures + raw counters of `kernel` in `workload` from profiles/r03_pmc.json, note).  None when there is no record or
+    it was measured on different sources of the workload's files than the loaded library was built from."""
+    if "rec" not in _pmc_cache:
+        try:
+            with open(PMC_RECORD) as f:
+                _pmc_cache["rec"] = json.load(f)
+        except (OSError, ValueError):
+            _pmc_cache["rec"] = {}
+    w = _pmc_cache["rec"].get(workload)
+    if not w or kernel not in w.get("kernels", {}):
+        return None, "no PMC record for this kernel"
+    sha = w.get("source_sha1", {})
+    stale = {fn: (sha.get(fn), build_id.get(fn)) for fn in PMC_SOURCES.get(workload, ()) if fn in build_id and sha.get(fn) != build_id.get(fn)}
+    if stale:
+        return None, "PMC record is stale (measured on / library built from: %s)" % stale
+    return w["kernels"][kernel], "profiles/%s [%s]" % (os.path.basename(PMC_RECORD), workload)
+
+
+def floors_of(rec, launch_ms):
+    """the pipe floors of a kernel next to its HBM fraction ('report both'): time the counted work needs on each pipe at its
+    measured peak rate (tools/r03_records.py states the formulas), the largest = compute_floor_ms, and its share of the launch"""
+    if not rec:
+        return {}
+    d = rec.get("derived", {})
+    fl = {k: d[k] for k in ("valu_floor_ms", "lds_floor_ms", "mfma_floor_ms", "hbm_floor_ms") if k in d}
+    comp = {k: v for k, v in fl.items() if k != "hbm_floor_ms"}
+    out = dict(fl)
+    if comp:
+        top = max(comp, key=comp.get)
+        out["compute_floor_ms"] = comp[top]
+        out["compute_floor_pipe"] = top[:-len("_floor_ms")]
+        if launch_ms:
+            out["compute_frac"] = round(comp[top] / launch_ms, 4)
+    if "mfma_busy" in d:
+        out["mfma_busy_pmc"] = d["mfma_busy"]
+    return out
 
 
 def synthetic_batch(B, rank, n_classes):
@@ -93,6 +138,7 @@ def kernel_models(B, C):
     m["conv_wgrad_bf16<64,128>"] = ("mfma", 2.0 * B * 12 * 9 * 64 * 128)
     m["conv_dgrad<128,64>"] = ("mfma", 2.0 * B * 12 * 9 * 64 * 128)
     m["conv_dgrad<128,128>"] = ("mfma", 2.0 * B * 256 * 128)
+    m["head_fwd_bwd_kernel"] = ("mfma", 3.0 * 2.0 * B * 128 * C)           # logits, dW2 and dx in one kernel (the fused head of the train step)
     m["head_fwd_kernel"] = ("mfma", 2.0 * B * 128 * C)
     m["head_bwd_kernel"] = ("mfma", 2.0 * 2.0 * B * 128 * C)              # dW2 and dx
     for l in range(1, 4):
@@ -245,6 +291,28 @@ def time_graph(session, reps, torch):
     return e0.elapsed_time(e1) / reps
 
 
+def kernel_roofline(workload, rep, n_launch, alg, L):
+    """roofline objects of a side workload's kernels: rep = kws_prof_report() over n_launch iterations, alg = {kernel: (bound, algorithmic
+    bytes or flops per launch)}.  -> {"dominant": name, kernel: {bound, achieved, peak, unit, frac, avg_launch_ms, floors from the PMC record}}"""
+    out = {}
+    for k, (bound, amount) in alg.items():
+        if k not in rep:
+            continue
+        ms = rep[k]["total_ms"] / rep[k]["count"]
+        if bound == "mfma":
+            ach, peak, unit = amount / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = amount / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        prec, note = pmc_record(workload, k, L.build_id())
+        e = {"bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "avg_launch_ms": round(ms, 5),
+             "ms_per_iteration": round(rep[k]["total_ms"] / n_launch, 5), "traffic": (prec or {}).get("derived", {}).get("hbm_bytes"), "pmc_note": note}
+        e.update(floors_of(prec, ms))
+        out[k] = e
+    if out:
+        out["dominant"] = max((k for k in out), key=lambda k: out[k]["ms_per_iteration"])
+    return out
+
+
 def extra_workloads(torch, pr, feat_fn, reps):
     import kws_amd.lib as L
     from kws_amd.inference import InferenceSession
@@ -273,6 +341,17 @@ def extra_workloads(torch, pr, feat_fn, reps):
                         "clips_per_s": round(cps, 1), "hbm_roofline_clips_per_s": round(HBM_PEAK_GBS * 1e9 / FWD_BYTES_PER_CLIP, 1),
                         "hbm_roofline_frac": round(cps * FWD_BYTES_PER_CLIP / (HBM_PEAK_GBS * 1e9), 4),
                         "kernel_ms": {k: round(v["total_ms"] / 5, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}}
+    # the FLOP-side ceiling next to the HBM fraction: the summed pipe floors of the forward's kernels from the PMC record of this workload
+    fl = {}
+    for k in rep:
+        r, _ = pmc_record("infer" if not k.startswith("featurize") else "feat", k, L.build_id())
+        for n, v in floors_of(r, None).items():
+            if n.endswith("_floor_ms"):
+                fl[n] = round(fl.get(n, 0.0) + v, 5)
+    if fl:
+        out["fwd_infer"]["floors_ms_sum_over_kernels"] = fl
+        out["fwd_infer"]["compute_ceiling_clips_per_s"] = round(4096 / max(fl.get("compute_floor_ms", 0.0), 1e-9) * 1e3, 1)
+        out["fwd_infer"]["compute_ceiling_note"] = "sum over the forward's kernels of each kernel's largest pipe floor (vector ALU / LDS / matrix): what the counted work needs with perfect overlap inside every kernel and none between kernels"
     del s, eager, dm
     # (iii) simple_gru train step, B = 2048 (BASELINE configs[2]): featurize + fwd + bwd + Adam, pipelined like the headline step
     B = 2048
@@ -310,6 +389,18 @@ def extra_workloads(torch, pr, feat_fn, reps):
     log("extra: gru_train %.4f ms" % ms)
     out["gru_train"] = {"workload": "configs[2]: featurize + simple_gru fwd + bwd + Adam, B = 2048, 36 classes", "ms_per_step": round(ms, 4),
                         "clips_per_s": round(B / ms * 1e3, 1), "final_loss": round(float(dm.stats[0].item()) / B, 4)}
+    # per-kernel times of the same pipelined execution, and the roofline of its kernels: the recurrence is 30 DEPENDENT steps per clip block
+    # (16 clips per block: 128 blocks at B = 2048, i.e. half of the 256 CUs), so the kernels are latency-bound; the figures say how far
+    L.prof_enable(True)
+    gru_steps(10, 1000)
+    torch.cuda.synchronize()
+    rep = L.prof_report()
+    L.prof_enable(False)
+    T, F, H = pr.n_features, pr.feature_size, 48
+    fwd_flops = 2.0 * B * T * (F * 3 * H + H * 3 * H)
+    out["gru_train"]["kernel_ms"] = {k: round(v["total_ms"] / 10, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}
+    out["gru_train"]["roofline"] = kernel_roofline("gru", rep, 10, {"gru_fwd_kernel": ("mfma", fwd_flops), "gru_bwd_kernel": ("mfma", 2.0 * fwd_flops + 2.0 * B * T * H * 3 * H),
+                                                                  "featurize_fft1024_f32": ("hbm", B * FEAT_BYTES_PER_CLIP)}, L)
     del pipe, dm
     # (iv) simple_cnn_lite fp16 inference, B = 16 384, hipGraph-captured featurize + forward (BASELINE configs[4])
     B = 16384
@@ -326,6 +417,21 @@ def extra_workloads(torch, pr, feat_fn, reps):
         log("extra: lite fp16 %s %.4f ms" % (name, ms))
         lite[name] = {"ms": round(ms, 4), "clips_per_s": round(B / ms * 1e3, 1), "bytes_per_clip": nbytes,
                       "hbm_roofline_frac": round(B / ms * 1e3 * nbytes / (HBM_PEAK_GBS * 1e9), 4)}
+        if name == "f32_in":
+            eager = InferenceSession(dm, feat_fn, B, wav_dtype=dt, use_graph=False, fp16=True)      # per-kernel times of the same forward, eager
+            eager.wav.copy_(s.wav)
+            L.prof_enable(True)
+            for _ in range(5):
+                eager.run()
+            torch.cuda.synchronize()
+            rep = L.prof_report()
+            L.prof_enable(False)
+            lite["kernel_ms"] = {k: round(v["total_ms"] / 5, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}
+            # algorithmic bytes: featurizer 64 000 in + 2 400 out; front kernel 2 400 in + 2 240 out (a2 as fp16); back kernel 2 240 in + 4 C out
+            lite["roofline"] = kernel_roofline("lite16", rep, 5, {"featurize_fft1024_f32": ("hbm", B * FEAT_BYTES_PER_CLIP),
+                                                                 "lite_front_infer_kernel": ("hbm", B * (2400.0 + 2240.0)),
+                                                                 "lite_back_f16_kernel": ("hbm", B * (2240.0 + 4.0 * N_CLASSES))}, L)
+            del eager
         del s, dm
     lite["workload"] = "configs[4]: featurize + simple_cnn_lite forward, fp16 activations / matrix operands with fp32 accumulation, B = 16384, one hipGraph replay per batch"
     out["lite_fp16_graph"] = lite
@@ -578,23 +684,10 @@ def main():
             ach, peak, unit = amount / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
         else:
             ach, peak, unit = amount / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-        # HBM bytes per launch from the PMC passes recorded in profiles/ (bench.py cannot run rocprofv3 around itself); a record
-        # is only used if it was measured on the SAME source of the kernel's file as the loaded library was built from
-        traffic, traffic_note = None, "no PMC record for this kernel"
-        try:
-            with open(TRAFFIC_RECORD) as f:
-                trec = json.load(f)
-            rec = trec.get(name)
-            if rec and rec.get("batch") == B:
-                bid = L.build_id()
-                srcs = rec.get("sources") or {rec.get("source_file"): rec.get("source_sha1")}
-                if srcs and all(bid.get(fn) == sha for fn, sha in srcs.items()):
-                    traffic, traffic_note = rec["traffic_bytes_per_launch"], "profiles/%s" % os.path.basename(TRAFFIC_RECORD)
-                else:
-                    traffic_note = "PMC record is stale (measured on %s, library built from %s)" % (
-                        srcs, {fn: bid.get(fn) for fn in srcs})
-        except (OSError, ValueError):
-            pass
+        # HBM bytes per launch and the pipe floors from the PMC passes recorded in profiles/ (bench.py cannot run rocprofv3 around itself); a
+        # record is only used if it was measured on the SAME sources of the kernel's files as the loaded library was built from
+        prec, traffic_note = pmc_record("feat_shared" if name.startswith("featurize") else "step", name, L.build_id())
+        traffic = (prec or {}).get("derived", {}).get("hbm_bytes")
         alone_ms = rep_serial[name]["total_ms"] / rep_serial[name]["count"]
         roofline = {"kernel": name, "bound": bound, "achieved": round(ach, 3), "peak": peak, "unit": unit,
                     "frac": round(ach / peak, 4), "traffic": traffic, "traffic_note": traffic_note, "avg_launch_ms": round(avg_ms, 5),
@@ -602,26 +695,25 @@ def main():
                     # the same kernel when nothing else shares the chip (second profile pass): the pipelined step runs it
                     # next to the model kernels, which stretches its launch but shortens the step
                     "alone_launch_ms": round(alone_ms, 5), "alone_frac": round(ach * avg_ms / alone_ms / peak, 4)}
+        # the FLOP-side ceiling next to the HBM fraction: what the counted vector-ALU / LDS / matrix work of a launch needs at the pipes' peak rates
+        roofline.update(floors_of(prec, avg_ms))
         # the dense head (Dense(256->128) as a 2x1 'valid' conv + Dense(C) softmax head), forward and backward: the only dense
         # contractions of the model -> matrix-core figures (north star: "MFMA utilisation for the dense head")
         dh = {}
         fl_tot, ms_tot = 0.0, 0.0
         for k in ("conv_bf16_fwd<128,128>", "conv_gemm_fwd<128,128>", "conv_bf16_dgrad<128,128>", "conv_dgrad<128,128>", "conv_wgrad<128,128>",
-                  "head_fwd_kernel", "head_bwd_kernel"):
+                  "head_fwd_bwd_kernel", "head_fwd_kernel", "head_bwd_kernel"):
             if k in rep_serial and k in models:
                 ms_k = rep_serial[k]["total_ms"] / rep_serial[k]["count"]
                 dh[k] = {"ms": round(ms_k, 5), "algorithmic_tflops": round(models[k][1] / (ms_k * 1e-3) / 1e12, 3)}
                 fl_tot += models[k][1]
                 ms_tot += ms_k
-        pmc = None
-        try:
-            with open(PMC_RECORD) as f:
-                prec = json.load(f)
-            bid = L.build_id()
-            if all(bid.get(fn) == sha for fn, sha in prec.get("source_sha1", {}).items()):
-                pmc = prec.get("kernels")
-        except (OSError, ValueError):
-            pass
+        pmc = {}
+        for k in dh:
+            r, _ = pmc_record("step", k, L.build_id())
+            if r:
+                pmc[k] = {n: r["derived"].get(n) for n in ("mfma_busy", "mfma_floor_ms", "valu_floor_ms", "lds_floor_ms", "hbm_read_MB", "hbm_write_MB")}
+        pmc = pmc or None
         dense_head = {"kernels": dh, "algorithmic_tflops": round(fl_tot / (ms_tot * 1e-3) / 1e12, 3) if ms_tot else None,
                       "frac_of_fp32_matrix_peak": round(fl_tot / (ms_tot * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if ms_tot else None,
                       "note": "serial-pass HIP-event times; split-precision kernels issue 6 bf16 MFMA partial products per algorithmic MAC, so their "

@@ -1,0 +1,251 @@
+// csrc/kws_infer_fused.h -- inference forward of simple_cnn (classifier/models/cnn.py:44-66, classifier/model.py:37) behind the second
+// pooling stage as ONE kernel: conv3 (3x3, stride 2) -> BN -> ReLU6 -> conv4 (3x3, relu) -> BN -> ReLU6 -> MaxPool -> Flatten ->
+// Dense(128) + ReLU6 -> Dense(C) + softmax, for the default geometry (a2 = 7 x 5 x 32 per clip).
+//
+// Before: five launches (conv3, conv4, activation + pool, dense, head) of 19 + 47 + 5 + 17 + 12 us at B = 4096, each a latency-bound
+// stage -> barrier -> multiply sequence with its activations making an HBM round trip, against ~25 us of matrix time.  Here a block owns
+// 16 clips for the whole chain:
+//   * the MFMA row tile IS the clip group: row = clip, one tile per pixel position, so the (position, tap) pairs that fall into the
+//     padding are skipped as whole tiles (38 of 108 pairs in both convolutions) and the A fragment of (position, tap) is simply the 16
+//     clips' channel vectors at one input pixel: activations live in LDS as [pixel][clip][channels] in fp32;
+//   * fp32 rows, split into the h / m / l bf16 planes of the three-way product (kws_device.h) IN REGISTERS when a fragment is read: 4 B per
+//     element of LDS instead of 6 (a2 and a3 together: 145 KB, one block per CU), two ds_read_b128 per fragment instead of three.  Rows are
+//     padded to 16 B x (2 mod 4) and a lane's 8 k-values are the two 4-float units lq and lq + 4 of the 32-channel step, which makes
+//     the ds_read_b128 lane groups conflict-free; the weights are prepared in the same k order;
+//   * the weights never touch LDS: infer_frag_kernel lays every (layer, k-step, column tile, plane) out as the 64 x 16 B a wave loads
+//     with one coalesced instruction (768 KB in all, L2-resident), loaded one k-step ahead;
+//   * eight waves: a wave owns one 16-channel column tile of conv4 / Dense for all 12 positions (conv3: one column tile x 6 positions),
+//     so a block reads every weight fragment exactly once; two waves per SIMD let one wave's splitting run under the other's MFMAs.
+#pragma once
+
+namespace kws {
+
+constexpr int kFuClips = 16;                      // clips per block = MFMA rows
+constexpr int kFuH2 = 7, kFuW2 = 5, kFuC2 = 32;   // a2: input of conv3
+constexpr int kFuH3 = 4, kFuW3 = 3, kFuC3 = 64;   // conv3 output (stride 2, 'same': pad 1 before on both axes)
+constexpr int kFuC4 = 128, kFuH4 = 2, kFuW4 = 1;  // conv4 output 4 x 3 x 128, pooled 2 x 1 x 128
+constexpr int kFuFlat = kFuH4 * kFuW4 * kFuC4;    // 256
+constexpr int kFuD = 128;                         // Dense units
+constexpr int kFuHeadCols = 48;                   // classes padded to three column tiles
+constexpr int kFuRS2 = kFuC2 + 8, kFuRS3 = kFuC3 + 8, kFuRS4 = kFuFlat + 8, kFuRSD = kFuD + 8;   // row strides in floats: 16 B x (2 mod 4)
+constexpr int kFuA2 = kFuH2 * kFuW2 * kFuClips * kFuRS2;        // 22 400 floats
+constexpr int kFuA3 = kFuH3 * kFuW3 * kFuClips * kFuRS3;        // 13 824 floats
+constexpr int kFuLdsBytes = 4 * (kFuA2 + kFuA3);                // 144 896 B
+constexpr int kFuThreads = 512;
+static_assert(kFuClips * (kFuRS4 + kFuRSD + kFuHeadCols + 2) <= kFuA2, "the tail of the chain lives in a2's region");
+
+// fragment-major weight planes: element ((ks * NCT + ct) * 64 + lane) * 8 + j of plane p = plane p of W[k(ks, lane >> 4, j)][16 ct + (lane & 15)],
+// k-step ks = tap * (CI / 32) + chunk, channel = 32 chunk + 4 (lane >> 4) + (j & 3) + 16 (j >> 2); W in Keras HWIO order [(tap * CI + ci) * CO + co]
+struct FragDesc { const float *w; __bf16 *p[3]; int taps, ci, co, nct; };
+struct FragDescs { FragDesc d[4]; };
+__global__ __launch_bounds__(256) void infer_frag_kernel(FragDescs all)
+{
+    const FragDesc &d = all.d[blockIdx.y];
+    const int ksteps = d.taps * (d.ci / 32);
+    const long total = (long)ksteps * d.nct * 512;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const long f = i >> 9;
+        const int ct = (int)(f % d.nct), ks = (int)(f / d.nct);
+        const int tap = ks / (d.ci / 32), chunk = ks - tap * (d.ci / 32);
+        const int ch = 32 * chunk + 4 * (lane >> 4) + (j & 3) + 16 * (j >> 2), col = 16 * ct + (lane & 15);
+        const float v = col < d.co ? d.w[((long)tap * d.ci + ch) * d.co + col] : 0.f;
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        d.p[0][i] = h; d.p[1][i] = m; d.p[2][i] = (__bf16)(r1 - (float)m);
+    }
+}
+
+struct FusedTailArgs {
+    const float *a2;                  // (B, 7, 5, 32)
+    const __bf16 *f3[3], *f4[3], *fd[3], *fh[3];     // fragment-major planes of conv3 / conv4 / dense / head
+    const float *sc3, *sh3, *sc4, *sh4;              // folded BatchNorm coefficients of layers 3 and 4
+    const float *db, *hb;             // dense bias, head bias
+    float *probs;                     // (B, C) or nullptr
+    int32_t *argmax;                  // (B) or nullptr
+    int B, C;
+};
+
+__device__ __forceinline__ void fu_split(const f32x4 lo, const f32x4 hi, bf16x8 (&a)[3])
+{
+    bf16x4 h0, m0, l0, h1, m1, l1;
+    split_bf16(lo, h0, m0, l0);
+    split_bf16(hi, h1, m1, l1);
+    a[0] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    a[1] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
+    a[2] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// the A fragment of this lane: 8 floats of its row (clip li) at the k-step's units lq and lq + 4
+__device__ __forceinline__ void fu_load_a(const float *row, bf16x8 (&a)[3])
+{
+    const f32x4 lo = *reinterpret_cast<const f32x4 *>(row), hi = *reinterpret_cast<const f32x4 *>(row + 16);
+    fu_split(lo, hi, a);
+}
+__device__ __forceinline__ void fu_load_b(const __bf16 *const (&pl)[3], long frag, int lane, bf16x8 (&b)[3])
+{
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8 *>(pl[p] + (frag * 64 + lane) * 8);
+}
+
+__global__ __launch_bounds__(kFuThreads, 1) void infer_tail_kernel(FusedTailArgs g)
+{
+    extern __shared__ __attribute__((aligned(16))) float fu_lds[];
+    float *A2 = fu_lds, *A3 = fu_lds + kFuA2;
+    float *A4 = fu_lds, *D1 = A4 + kFuClips * kFuRS4, *LG = D1 + kFuClips * kFuRSD, *MS = LG + kFuClips * kFuHeadCols;   // alias a2 once conv3 is done
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lq = lane >> 4;
+    const int b0 = blockIdx.x * kFuClips;
+
+    // ---- a2 of the block's clips -> LDS [pixel][clip][32 (+8)] ----
+    {
+        constexpr int PER = kFuH2 * kFuW2 * kFuC2 / 4;                          // float4 per clip: 280
+        for (int i = tid; i < kFuClips * PER; i += kFuThreads) {
+            const int c = i / PER, r = i - c * PER, px = r >> 3, u = r & 7;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b0 + c < g.B) v = *reinterpret_cast<const f32x4 *>(g.a2 + ((long)(b0 + c) * PER + r) * 4);
+            *reinterpret_cast<f32x4 *>(A2 + (px * kFuClips + c) * kFuRS2 + 4 * u) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- conv3: wave = (column tile ct of 4, half of the 12 positions) ----
+    {
+        const int ct = wave & 3, half = wave >> 2;
+        f32x4 acc[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 bcur[3], bnext[3];
+        fu_load_b(g.f3, ct, lane, bcur);
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) fu_load_b(g.f3, (tap + 1) * 4 + ct, lane, bnext);
+            const int kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const int pos = 6 * half + q, oh = pos / kFuW3, ow = pos - oh * kFuW3;
+                const int ih = 2 * oh + kh - 1, iw = 2 * ow + kw - 1;
+                if (ih >= 0 && ih < kFuH2 && iw >= 0 && iw < kFuW2) {           // wave-uniform: the padding taps of this position are skipped
+                    bf16x8 a[3];
+                    fu_load_a(A2 + ((ih * kFuW2 + iw) * kFuClips + li) * kFuRS2 + 4 * lq, a);
+                    acc[q] = mfma_bf16x6(a, bcur, acc[q]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bcur[p] = bnext[p];
+        }
+        // BatchNorm (moving statistics, folded) + ReLU6 -> a3 [position][clip][64 (+8)]
+        const int ch = 16 * ct + li;
+        const float sc = g.sc3[ch], sh = g.sh3[ch];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int pos = 6 * half + q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A3[(pos * kFuClips + 4 * lq + r) * kFuRS3 + ch] = relu6f(fmaf(acc[q][r], sc, sh));
+        }
+    }
+    __syncthreads();
+
+    // ---- conv4 (activation='relu') -> BN -> ReLU6 -> 2 x 2 max-pool: wave = column tile (8 of 16 channels), all 12 positions ----
+    {
+        const int ct = wave;
+        f32x4 acc[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 bcur[3], bnext[3];
+        fu_load_b(g.f4, ct, lane, bcur);
+        for (int ks = 0; ks < 18; ++ks) {
+            if (ks + 1 < 18) fu_load_b(g.f4, (long)(ks + 1) * 8 + ct, lane, bnext);
+            const int tap = ks >> 1, chunk = ks & 1, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll
+            for (int pos = 0; pos < 12; ++pos) {
+                const int oh = pos / kFuW3, ow = pos - oh * kFuW3;
+                const int ih = oh + kh - 1, iw = ow + kw - 1;
+                if (ih >= 0 && ih < kFuH3 && iw >= 0 && iw < kFuW3) {
+                    bf16x8 a[3];
+                    fu_load_a(A3 + ((ih * kFuW3 + iw) * kFuClips + li) * kFuRS3 + 32 * chunk + 4 * lq, a);
+                    acc[pos] = mfma_bf16x6(a, bcur, acc[pos]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bcur[p] = bnext[p];
+        }
+        const int ch = 16 * ct + li;
+        const float sc = g.sc4[ch], sh = g.sh4[ch];
+#pragma unroll
+        for (int ph = 0; ph < kFuH4; ++ph)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float best = 0.f;                                                // ReLU6 outputs are >= 0
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int pos = (2 * ph + dy) * kFuW3 + dx;              // pooled column 0 = columns 0, 1 (column 2 is dropped: 'valid')
+                        best = fmaxf(best, relu6f(fmaf(fmaxf(acc[pos][r], 0.f), sc, sh)));
+                    }
+                A4[(4 * lq + r) * kFuRS4 + ph * kFuW4 * kFuC4 + ch] = best;      // Flatten is (h, w, c)
+            }
+    }
+    __syncthreads();
+
+    // ---- Dense(128) + ReLU6: wave = column tile ----
+    {
+        const int ct = wave;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        bf16x8 bcur[3], bnext[3];
+        fu_load_b(g.fd, ct, lane, bcur);
+#pragma unroll
+        for (int ks = 0; ks < kFuFlat / 32; ++ks) {
+            if (ks + 1 < kFuFlat / 32) fu_load_b(g.fd, (long)(ks + 1) * 8 + ct, lane, bnext);
+            bf16x8 a[3];
+            fu_load_a(A4 + li * kFuRS4 + 32 * ks + 4 * lq, a);
+            acc = mfma_bf16x6(a, bcur, acc);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bcur[p] = bnext[p];
+        }
+        const int ch = 16 * ct + li;
+        const float bias = g.db[ch];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D1[(4 * lq + r) * kFuRSD + ch] = relu6f(acc[r] + bias);
+    }
+    __syncthreads();
+
+    // ---- Dense(C): waves 0..2 = column tiles ----
+    if (wave < kFuHeadCols / 16) {
+        const int ct = wave;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < kFuD / 32; ++ks) {
+            bf16x8 a[3], b[3];
+            fu_load_b(g.fh, (long)ks * (kFuHeadCols / 16) + ct, lane, b);
+            fu_load_a(D1 + li * kFuRSD + 32 * ks + 4 * lq, a);
+            acc = mfma_bf16x6(a, b, acc);
+        }
+        const int col = 16 * ct + li;
+        const float bias = col < g.C ? g.hb[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) LG[(4 * lq + r) * kFuHeadCols + col] = acc[r] + bias;
+    }
+    __syncthreads();
+
+    // ---- softmax / arg-max per clip (first maximum wins, like np.argmax) ----
+    if (tid < kFuClips) {
+        const float *x = LG + tid * kFuHeadCols;
+        float mx = x[0];
+        int am = 0;
+        for (int c = 1; c < g.C; ++c)
+            if (x[c] > mx) { mx = x[c]; am = c; }
+        float s = 0.f;
+        for (int c = 0; c < g.C; ++c) s += expf(x[c] - mx);
+        MS[2 * tid] = mx;
+        MS[2 * tid + 1] = 1.0f / s;
+        if (g.argmax && b0 + tid < g.B) g.argmax[b0 + tid] = am;
+    }
+    __syncthreads();
+    if (g.probs)
+        for (int i = tid; i < kFuClips * g.C; i += kFuThreads) {
+            const int c = i / g.C, col = i - c * g.C;
+            if (b0 + c < g.B) g.probs[(long)(b0 + c) * g.C + col] = expf(LG[c * kFuHeadCols + col] - MS[2 * c]) * MS[2 * c + 1];
+        }
+}
+
+}  // namespace kws

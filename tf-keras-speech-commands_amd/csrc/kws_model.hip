@@ -17,6 +17,7 @@
 #include "kws_layer1_fast.h"
 #include "kws_lite.h"
 #include "kws_lite_f16.h"
+#include "kws_infer_fused.h"
 
 using namespace kws;
 
@@ -360,6 +361,40 @@ static int split_weights(const kws_model *m, const float *params, CnnWs &w, hipS
     return KWS_OK;
 }
 
+// Inference of simple_cnn in split precision at the default geometry: everything behind the second pooling stage is ONE kernel
+// (kws_infer_fused.h).  Its weights are prepared fragment-major; they take the place of the transposed planes (same element counts), the
+// head's go to the head of the double partial slab (unused by the inference forward).
+static bool fused_tail_ok(const kws_model *m, bool bf16)
+{
+    const CnnDims &d = m->d;
+    return bf16 && m->kind == KWS_SIMPLE_CNN && d.H2 == kFuH2 && d.W2 == kFuW2 && d.H3 == kFuH3 && d.W3 == kFuW3 && d.H4 == kFuH4 && d.W4 == kFuW4 &&
+           m->C <= kFuHeadCols;
+}
+static __bf16 *fused_head_plane(CnnWs &w, int p) { return reinterpret_cast<__bf16 *>(w.partial) + (size_t)p * (kFuD / 32) * (kFuHeadCols / 16) * 512; }
+static int split_weights_fused(const kws_model *m, const float *params, CnnWs &w, hipStream_t s)
+{
+    FragDescs all{};
+    all.d[0] = FragDesc{params + m->o_k[2], {w.wsp[0][3], w.wsp[0][4], w.wsp[0][5]}, 9, kFuC2, kFuC3, kFuC3 / 16};
+    all.d[1] = FragDesc{params + m->o_k[3], {w.wsp[1][3], w.wsp[1][4], w.wsp[1][5]}, 9, kFuC3, kFuC4, kFuC4 / 16};
+    all.d[2] = FragDesc{params + m->o_dk, {w.wsp[2][3], w.wsp[2][4], w.wsp[2][5]}, kFuH4 * kFuW4, kFuC4, kFuD, kFuD / 16};
+    all.d[3] = FragDesc{params + m->o_hk, {fused_head_plane(w, 0), fused_head_plane(w, 1), fused_head_plane(w, 2)}, 1, kFuD, m->C, kFuHeadCols / 16};
+    KWS_LAUNCH("infer_frag_kernel", infer_frag_kernel, dim3(32, 4), dim3(256), 0, s, all);
+    return KWS_OK;
+}
+static int launch_fused_tail(const kws_model *m, int B, const float *params, CnnWs &w, float *probs, int32_t *argmax, hipStream_t s)
+{
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(infer_tail_kernel), kFuLdsBytes)) return rc;
+    FusedTailArgs a{};
+    a.a2 = w.a[1];
+    for (int p = 0; p < 3; ++p) { a.f3[p] = w.wsp[0][3 + p]; a.f4[p] = w.wsp[1][3 + p]; a.fd[p] = w.wsp[2][3 + p]; a.fh[p] = fused_head_plane(w, p); }
+    const BnCoef k3 = coef_of(w.coef[2], 64), k4 = coef_of(w.coef[3], 128);
+    a.sc3 = k3.scale; a.sh3 = k3.shift; a.sc4 = k4.scale; a.sh4 = k4.shift;
+    a.db = params + m->o_db; a.hb = params + m->o_hb;
+    a.probs = probs; a.argmax = argmax; a.B = B; a.C = m->C;
+    KWS_LAUNCH("infer_tail_kernel", infer_tail_kernel, dim3(blocks_for(B, kFuClips)), dim3(kFuThreads), (size_t)kFuLdsBytes, s, a);
+    return KWS_OK;
+}
+
 ConvGeom geom3x3(int B, int H, int W, int stride)
 {
     ConvGeom g;
@@ -390,7 +425,7 @@ constexpr int kPrepSplitBlocks = 16, kPrepZeroBlocks = 16, kPrepBlocks = 3 * kPr
 // stream beside the weight split instead of on the main chain; *zeroed tells the caller whether that happened
 int cnn_forward(const kws_model *m, const float *feat, int B, const float *params, float *state, CnnWs &w, bool training,
                 uint64_t seed, hipStream_t s, float *zero_grads = nullptr, bool *zeroed = nullptr, OverlapHook *hook = nullptr,
-                const double *moments = nullptr)
+                const double *moments = nullptr, float *probs = nullptr, int32_t *argmax = nullptr, bool *head_done = nullptr)
 {
     const DisarmOnExit disarm_guard;        // no armed fork event outlives this call, whichever way it returns
     const CnnDims &d = m->d;
@@ -402,6 +437,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool bf16 = matrix_prec(m) == 1;
     // inference after kws_model_prepare_inference on the same buffers: the weight planes and BatchNorm coefficients are in place
     const bool prepared = !training && m->prepared_for(params, state, w.base, B, matrix_prec(m), infer_prec(m));
+    // inference with a caller that takes the head's outputs here: conv3 .. softmax as one kernel (kws_infer_fused.h)
+    const bool fused_tail = !training && head_done && fused_tail_ok(m, bf16);
     ModelRes *R = nullptr;       // only the split-on-the-side-stream branch below needs the model's stream / events
     // training in split precision at a geometry the MFMA layer-1 kernels cover: the weight split and the gradient clear ride
     // in the grid of the layer-1 activation kernel -- no side-stream branch, no events
@@ -426,7 +463,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         // inference stays on ONE stream: callers capture it into hipGraphs, and a fork to the library's side stream inside
         // several captured graphs made every graph after the first replay 0.2 ms slower
         if (!prepared)
-            if (int rc = split_weights(m, params, w, s)) return rc;
+            if (int rc = fused_tail ? split_weights_fused(m, params, w, s) : split_weights(m, params, w, s)) return rc;
     }
     if (!training && !prepared)
         if (int rc = infer_coefs(m, params, state, w, s)) return rc;
@@ -499,6 +536,12 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                 const BnCoef k2 = coef_of(w.coef[1], 32);
                 KWS_LAUNCH("conv_fwd_clip_pool_bf16<16,32>", (conv_fwd_clip_bf16_kernel<false, true>), dim3(nblk), dim3(256), smb, s, in, kern, w.a[1], B,
                            Hs[1], Ws[1], w.partial, kStatStride, k2.scale, k2.shift);
+                if (fused_tail) {
+                    KWS_TRY(launch_fused_tail(m, B, params, w, probs, argmax, s));
+                    *head_done = true;
+                    KWS_LAUNCH_CHECK("simple_cnn forward");
+                    return KWS_OK;
+                }
                 continue;
             } else {
                 // inference: BatchNorm affine + ReLU6 + 2x2 max in the kernel's epilogue, a2 written directly
@@ -1185,7 +1228,7 @@ int kws_model_prepare_inference(kws_model *m, int B, const float *params, const 
     if (int rc = check_ws(m, B, false, ws, ws_bytes, w)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     KWS_TRY(infer_coefs(m, params, state, w, s));
-    if (m->kind == KWS_SIMPLE_CNN && matrix_prec(m) == 1) KWS_TRY(split_weights(m, params, w, s));
+    if (m->kind == KWS_SIMPLE_CNN && matrix_prec(m) == 1) KWS_TRY(fused_tail_ok(m, true) ? split_weights_fused(m, params, w, s) : split_weights(m, params, w, s));
     if (m->kind == KWS_SIMPLE_CNN_LITE && infer_prec(m) == KWS_INFER_FP16)
         KWS_LAUNCH("lite_f16_prepare_kernel", lite_f16_prepare_kernel, dim3(32), dim3(256), 0, s, params + m->o_pwk[2], params + m->o_pwk[3],
                    params + m->o_dk, params + m->o_hk, m->C, m->d.flat, reinterpret_cast<_Float16 *>(w.partial));
@@ -1348,9 +1391,11 @@ int kws_model_forward(kws_model *m, const float *feat, int B, const float *param
     if (m->prep.ws == ws && !m->prepared_for(params, state, ws, B, matrix_prec(m), infer_prec(m))) m->prep = kws_model::Prepared{};
     if (m->kind == KWS_SIMPLE_CNN_LITE && infer_prec(m) == KWS_INFER_FP16)
         return lite_forward_f16(m, feat, B, params, state, w, probs, argmax, s);
+    bool head_done = false;
     rc = m->kind == KWS_SIMPLE_CNN_LITE ? lite_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s)
-                                        : cnn_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s);
-    if (rc) return rc;
+                                        : cnn_forward(m, feat, B, params, const_cast<float *>(state), w, false, 0, s, nullptr, nullptr, nullptr, nullptr,
+                                                      probs, argmax, &head_done);
+    if (rc || head_done) return rc;
     return run_head(m, B, params, w.d1, w.loss_i, w.correct_i, nullptr, nullptr, probs, argmax, nullptr, 0.f, nullptr, 0, s);
 }
 

@@ -24,12 +24,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 sys.path.insert(0, os.path.join(ROOT, "tf-keras-speech-commands_amd"))
 CLOCK_HZ, SIMDS, CUS, HBM = 2.4e9, 1024, 256, 8.0e12
-SETS = {"feat": "fetch,write,sqa,sqb,lds", "feat_shared": "sqa,lds", "step": "fetch,write,mfma,lds,sqa", "infer": "fetch,write,mfma,lds,sqa",
+SETS = {"feat": "fetch,write,sqa,sqb,lds", "feat_shared": "fetch,write,sqa,sqb,lds", "step": "fetch,write,mfma,lds,sqa", "infer": "fetch,write,mfma,lds,sqa",
         "gru": "fetch,write,mfma,lds,sqa", "lstm": "fetch,write,mfma,lds,sqa", "lite16": "fetch,write,mfma,lds,sqa"}
 # short names (the ones kws_prof_report / bench.py use) of the kernels the bench line carries roofline objects for
 SHORT = [("featurize_fft1024_v3_kernel<float", "featurize_fft1024_f32"), ("featurize_fft1024_v3_kernel<short", "featurize_fft1024_i16"),
          ("gru_fwd_kernel", "gru_fwd_kernel"), ("gru_bwd_kernel", "gru_bwd_kernel"), ("lstm_fwd_kernel", "lstm_fwd_kernel"),
-         ("lstm_bwd_kernel", "lstm_bwd_kernel"), ("lite_front_infer_kernel", "lite_front_infer_kernel"), ("lite_back_f16_kernel", "lite_back_f16_kernel")]
+         ("lstm_bwd_kernel", "lstm_bwd_kernel"), ("lite_front_infer_kernel", "lite_front_infer_kernel"), ("lite_back_f16_kernel", "lite_back_f16_kernel"),
+         # the train step's matrix kernels under the names kws_prof_report gives them
+         ("conv_wgrad_clip_bf16_kernel", "conv_wgrad_clip_bf16<16,32>"), ("conv_dgrad_clip_bf16_kernel", "conv_dgrad_clip_bf16<32,16>"),
+         ("conv_fwd_clip_bf16_kernel<true", "conv_fwd_clip_bf16<16,32>"), ("conv_fwd_clip_bf16_kernel<false", "conv_fwd_clip_pool_bf16<16,32>"),
+         ("conv_wgrad_bf16_kernel<64, 128", "conv_wgrad_bf16<64,128>"), ("conv_wgrad_bf16_kernel<32, 64", "conv_wgrad_bf16<32,64>"),
+         ("conv_bf16_kernel<32, 64, 0, 0", "conv_bf16_fwd<32,64>"), ("conv_bf16_kernel<32, 64, 0", "conv_bf16_fwd_bn<32,64>"),
+         ("conv_bf16_kernel<64, 128, 0", "conv_bf16_fwd<64,128>"), ("conv_bf16_kernel<128, 128, 0", "conv_bf16_fwd<128,128>"),
+         ("conv_bf16_kernel<128, 64, 1", "conv_bf16_dgrad<128,64>"), ("conv_bf16_kernel<128, 128, 1", "conv_bf16_dgrad<128,128>"),
+         ("conv_dgrad_direct_kernel<64, 32", "conv_dgrad<64,32>"), ("conv_wgrad_direct_kernel<128, 128", "conv_wgrad<128,128>"),
+         ("head_bwd_mfma_kernel<true", "head_fwd_bwd_kernel"), ("l1f_bwd_onepass_kernel", "l1m_bwd_onepass_kernel"),
+         ("l1m_act_pool_moments_kernel", "l1m_act_pool_kernel"), ("l1_moments_kernel", "l1_moments_kernel"), ("infer_tail_kernel", "infer_tail_kernel")]
 
 
 def derived(c, launches_note=None):

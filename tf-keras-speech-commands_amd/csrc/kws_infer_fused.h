@@ -8,10 +8,11 @@
 //   * the MFMA row tile IS the clip group: row = clip, one tile per pixel position, so the (position, tap) pairs that fall into the
 //     padding are skipped as whole tiles (38 of 108 pairs in both convolutions) and the A fragment of (position, tap) is simply the 16
 //     clips' channel vectors at one input pixel: activations live in LDS as [pixel][clip][channels] in fp32;
-//   * fp32 rows, split into the h / m / l bf16 planes of the three-way product (kws_device.h) IN REGISTERS when a fragment is read: 4 B per
-//     element of LDS instead of 6 (a2 and a3 together: 145 KB, one block per CU), two ds_read_b128 per fragment instead of three.  Rows are
-//     padded to 16 B x (2 mod 4) and a lane's 8 k-values are the two 4-float units lq and lq + 4 of the 32-channel step, which makes
-//     the ds_read_b128 lane groups conflict-free; the weights are prepared in the same k order;
+//   * a2 stays fp32 in LDS and is split into the h / m / l bf16 planes of the three-way product (kws_device.h) in registers when a fragment
+//     is read (conv3 is the small product); conv3's epilogue splits a3 ONCE per element into three bf16 planes, so conv4 -- 80 % of the
+//     arithmetic -- reads its A fragments with one ds_read_b128 per plane and no vector-ALU work (first version: fp32 a3 split on every
+//     read, 0.061 ms; every wave re-split every fragment).  Rows are 128 B (32 floats / 64 bf16) without padding; the 16-byte unit u of
+//     row (pixel, clip) sits at u ^ ((clip >> 1) & 7), which makes the ds_read_b128 lane groups {0-3,12-15,20-27}, ... conflict-free;
 //   * the weights never touch LDS: infer_frag_kernel lays every (layer, k-step, column tile, plane) out as the 64 x 16 B a wave loads
 //     with one coalesced instruction (768 KB in all, L2-resident), loaded one k-step ahead;
 //   * eight waves: a wave owns one 16-channel column tile of conv4 / Dense for all 12 positions (conv3: one column tile x 6 positions),
@@ -27,16 +28,18 @@ constexpr int kFuC4 = 128, kFuH4 = 2, kFuW4 = 1;  // conv4 output 4 x 3 x 128, p
 constexpr int kFuFlat = kFuH4 * kFuW4 * kFuC4;    // 256
 constexpr int kFuD = 128;                         // Dense units
 constexpr int kFuHeadCols = 48;                   // classes padded to three column tiles
-constexpr int kFuRS2 = kFuC2 + 8, kFuRS3 = kFuC3 + 8, kFuRS4 = kFuFlat + 8, kFuRSD = kFuD + 8;   // row strides in floats: 16 B x (2 mod 4)
-constexpr int kFuA2 = kFuH2 * kFuW2 * kFuClips * kFuRS2;        // 22 400 floats
-constexpr int kFuA3 = kFuH3 * kFuW3 * kFuClips * kFuRS3;        // 13 824 floats
-constexpr int kFuLdsBytes = 4 * (kFuA2 + kFuA3);                // 144 896 B
+constexpr int kFuRS4 = kFuFlat + 8, kFuRSD = kFuD + 8;         // row strides in floats of the small fp32 tiles: 16 B x (2 mod 4)
+constexpr int kFuA2 = kFuH2 * kFuW2 * kFuClips * kFuC2;         // floats: a2 [pixel][clip][32], swizzled units, 71 680 B
+constexpr int kFuA3P = kFuH3 * kFuW3 * kFuClips * kFuC3;        // bf16 per plane of a3 [position][clip][64], swizzled units
+constexpr int kFuLdsBytes = 4 * kFuA2 + 3 * 2 * kFuA3P;         // 145 408 B
 constexpr int kFuThreads = 512;
 static_assert(kFuClips * (kFuRS4 + kFuRSD + kFuHeadCols + 2) <= kFuA2, "the tail of the chain lives in a2's region");
 
 // fragment-major weight planes: element ((ks * NCT + ct) * 64 + lane) * 8 + j of plane p = plane p of W[k(ks, lane >> 4, j)][16 ct + (lane & 15)],
-// k-step ks = tap * (CI / 32) + chunk, channel = 32 chunk + 4 (lane >> 4) + (j & 3) + 16 (j >> 2); W in Keras HWIO order [(tap * CI + ci) * CO + co]
-struct FragDesc { const float *w; __bf16 *p[3]; int taps, ci, co, nct; };
+// k-step ks = tap * (CI / 32) + chunk; W in Keras HWIO order [(tap * CI + ci) * CO + co].  The k order inside a step follows the A side:
+// natural = 0 (A = fp32 rows: a lane's 8 values are the 4-float units lq and lq + 4): channel = 32 chunk + 4 (lane >> 4) + (j & 3) + 16 (j >> 2);
+// natural = 1 (A = bf16 planes: a lane's 8 values are ONE 16-byte unit): channel = 32 chunk + 8 (lane >> 4) + j
+struct FragDesc { const float *w; __bf16 *p[3]; int taps, ci, co, nct, natural; };
 struct FragDescs { FragDesc d[4]; };
 __global__ __launch_bounds__(256) void infer_frag_kernel(FragDescs all)
 {
@@ -48,7 +51,7 @@ __global__ __launch_bounds__(256) void infer_frag_kernel(FragDescs all)
         const long f = i >> 9;
         const int ct = (int)(f % d.nct), ks = (int)(f / d.nct);
         const int tap = ks / (d.ci / 32), chunk = ks - tap * (d.ci / 32);
-        const int ch = 32 * chunk + 4 * (lane >> 4) + (j & 3) + 16 * (j >> 2), col = 16 * ct + (lane & 15);
+        const int ch = 32 * chunk + (d.natural ? 8 * (lane >> 4) + j : 4 * (lane >> 4) + (j & 3) + 16 * (j >> 2)), col = 16 * ct + (lane & 15);
         const float v = col < d.co ? d.w[((long)tap * d.ci + ch) * d.co + col] : 0.f;
         const __bf16 h = (__bf16)v;
         const float r1 = v - (float)h;
@@ -91,82 +94,108 @@ __device__ __forceinline__ void fu_load_b(const __bf16 *const (&pl)[3], long fra
 __global__ __launch_bounds__(kFuThreads, 1) void infer_tail_kernel(FusedTailArgs g)
 {
     extern __shared__ __attribute__((aligned(16))) float fu_lds[];
-    float *A2 = fu_lds, *A3 = fu_lds + kFuA2;
+    float *A2 = fu_lds;
+    __bf16 *A3 = reinterpret_cast<__bf16 *>(fu_lds + kFuA2);                    // three planes of kFuA3P
     float *A4 = fu_lds, *D1 = A4 + kFuClips * kFuRS4, *LG = D1 + kFuClips * kFuRSD, *MS = LG + kFuClips * kFuHeadCols;   // alias a2 once conv3 is done
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lq = lane >> 4;
     const int b0 = blockIdx.x * kFuClips;
+    const int sw = (li >> 1) & 7;                                               // this lane's row (clip li) keeps unit u at u ^ sw
 
-    // ---- a2 of the block's clips -> LDS [pixel][clip][32 (+8)] ----
+    // conv3's first weight fragments are on their way while a2 is staged
+    const int ct3 = wave & 3, half3 = wave >> 2;
+    bf16x8 b3[3][3];
+    fu_load_b(g.f3, ct3, lane, b3[0]);
+    fu_load_b(g.f3, 4 + ct3, lane, b3[1]);
+
+    // ---- a2 of the block's clips -> LDS [pixel][clip][8 units of 4 floats], unit u at u ^ ((clip >> 1) & 7) ----
     {
         constexpr int PER = kFuH2 * kFuW2 * kFuC2 / 4;                          // float4 per clip: 280
         for (int i = tid; i < kFuClips * PER; i += kFuThreads) {
             const int c = i / PER, r = i - c * PER, px = r >> 3, u = r & 7;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (b0 + c < g.B) v = *reinterpret_cast<const f32x4 *>(g.a2 + ((long)(b0 + c) * PER + r) * 4);
-            *reinterpret_cast<f32x4 *>(A2 + (px * kFuClips + c) * kFuRS2 + 4 * u) = v;
+            *reinterpret_cast<f32x4 *>(A2 + ((px * kFuClips + c) * 8 + (u ^ ((c >> 1) & 7))) * 4) = v;
         }
     }
     __syncthreads();
 
-    // ---- conv3: wave = (column tile ct of 4, half of the 12 positions) ----
+    // ---- conv3: wave = (column tile ct of 4, half of the 12 positions); A = fp32 rows split in registers ----
     {
-        const int ct = wave & 3, half = wave >> 2;
         f32x4 acc[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 bcur[3], bnext[3];
-        fu_load_b(g.f3, ct, lane, bcur);
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap + 1 < 9) fu_load_b(g.f3, (tap + 1) * 4 + ct, lane, bnext);
-            const int kh = tap / 3, kw = tap - kh * 3;
+        const int o0 = 4 * (lq ^ sw), o1 = 4 * ((lq + 4) ^ sw);                  // the lane's two units of the 32-channel step
+#pragma unroll 1
+        for (int tap3 = 0; tap3 < 9; tap3 += 3) {                               // runtime loop: one kernel row per trip, its three taps unrolled
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const int pos = 6 * half + q, oh = pos / kFuW3, ow = pos - oh * kFuW3;
-                const int ih = 2 * oh + kh - 1, iw = 2 * ow + kw - 1;
-                if (ih >= 0 && ih < kFuH2 && iw >= 0 && iw < kFuW2) {           // wave-uniform: the padding taps of this position are skipped
-                    bf16x8 a[3];
-                    fu_load_a(A2 + ((ih * kFuW2 + iw) * kFuClips + li) * kFuRS2 + 4 * lq, a);
-                    acc[q] = mfma_bf16x6(a, bcur, acc[q]);
+            for (int d = 0; d < 3; ++d) {
+                const int tap = tap3 + d;
+                if (tap + 2 < 9) fu_load_b(g.f3, (tap + 2) * 4 + ct3, lane, b3[(d + 2) % 3]);     // two k-steps ahead
+                const int kh = tap3 / 3, kw = d;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int pos = 6 * half3 + q, oh = pos / kFuW3, ow = pos - oh * kFuW3;
+                    const int ih = 2 * oh + kh - 1, iw = 2 * ow + kw - 1;
+                    if (ih >= 0 && ih < kFuH2 && iw >= 0 && iw < kFuW2) {       // wave-uniform: the padding taps of this position are skipped
+                        const float *row = A2 + ((ih * kFuW2 + iw) * kFuClips + li) * kFuC2;
+                        bf16x8 a[3];
+                        fu_split(*reinterpret_cast<const f32x4 *>(row + o0), *reinterpret_cast<const f32x4 *>(row + o1), a);
+                        acc[q] = mfma_bf16x6(a, b3[d], acc[q]);
+                    }
                 }
             }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bcur[p] = bnext[p];
         }
-        // BatchNorm (moving statistics, folded) + ReLU6 -> a3 [position][clip][64 (+8)]
-        const int ch = 16 * ct + li;
+        // conv4's first weight fragments travel under the epilogue and the barrier
+        // BatchNorm (moving statistics, folded) + ReLU6 -> a3 as three bf16 planes [position][clip][8 units of 8], unit u at u ^ ((clip >> 1) & 7)
+        const int ch = 16 * ct3 + li;
         const float sc = g.sc3[ch], sh = g.sh3[ch];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            const int pos = 6 * half + q;
+            const int pos = 6 * half3 + q;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) A3[(pos * kFuClips + 4 * lq + r) * kFuRS3 + ch] = relu6f(fmaf(acc[q][r], sc, sh));
+            for (int r = 0; r < 4; ++r) {
+                const int clip = 4 * lq + r;
+                const float v = relu6f(fmaf(acc[q][r], sc, sh));
+                const __bf16 h = (__bf16)v;
+                const float r1 = v - (float)h;
+                const __bf16 m = (__bf16)r1;
+                const int e = ((pos * kFuClips + clip) * 8 + ((ch >> 3) ^ ((clip >> 1) & 7))) * 8 + (ch & 7);
+                A3[e] = h; A3[kFuA3P + e] = m; A3[2 * kFuA3P + e] = (__bf16)(r1 - (float)m);
+            }
         }
     }
+    bf16x8 b4[3][3];                                                            // conv4's weights: a ring of three k-steps
+    fu_load_b(g.f4, wave, lane, b4[0]);
+    fu_load_b(g.f4, 8 + wave, lane, b4[1]);
     __syncthreads();
 
-    // ---- conv4 (activation='relu') -> BN -> ReLU6 -> 2 x 2 max-pool: wave = column tile (8 of 16 channels), all 12 positions ----
+    // ---- conv4 (activation='relu') -> BN -> ReLU6 -> 2 x 2 max-pool: wave = column tile (8 of 16 channels), all 12 positions; A = bf16 planes ----
     {
         const int ct = wave;
         f32x4 acc[12];
 #pragma unroll
         for (int q = 0; q < 12; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 bcur[3], bnext[3];
-        fu_load_b(g.f4, ct, lane, bcur);
-        for (int ks = 0; ks < 18; ++ks) {
-            if (ks + 1 < 18) fu_load_b(g.f4, (long)(ks + 1) * 8 + ct, lane, bnext);
-            const int tap = ks >> 1, chunk = ks & 1, kh = tap / 3, kw = tap - kh * 3;
+#pragma unroll 1
+        for (int ks3 = 0; ks3 < 18; ks3 += 3) {
 #pragma unroll
-            for (int pos = 0; pos < 12; ++pos) {
-                const int oh = pos / kFuW3, ow = pos - oh * kFuW3;
-                const int ih = oh + kh - 1, iw = ow + kw - 1;
-                if (ih >= 0 && ih < kFuH3 && iw >= 0 && iw < kFuW3) {
-                    bf16x8 a[3];
-                    fu_load_a(A3 + ((ih * kFuW3 + iw) * kFuClips + li) * kFuRS3 + 32 * chunk + 4 * lq, a);
-                    acc[pos] = mfma_bf16x6(a, bcur, acc[pos]);
+            for (int d = 0; d < 3; ++d) {
+                const int ks = ks3 + d;
+                if (ks + 2 < 18) fu_load_b(g.f4, (long)(ks + 2) * 8 + ct, lane, b4[(d + 2) % 3]);   // two k-steps ahead
+                const int tap = ks >> 1, chunk = ks & 1, kh = tap / 3, kw = tap - kh * 3;
+                const int uo = ((4 * chunk + lq) ^ sw) * 8;
+#pragma unroll
+                for (int pos = 0; pos < 12; ++pos) {
+                    const int oh = pos / kFuW3, ow = pos - oh * kFuW3;
+                    const int ih = oh + kh - 1, iw = ow + kw - 1;
+                    if (ih >= 0 && ih < kFuH3 && iw >= 0 && iw < kFuW3) {
+                        const __bf16 *row = A3 + ((ih * kFuW3 + iw) * kFuClips + li) * kFuC3 + uo;
+                        bf16x8 a[3];
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(row + p * kFuA3P);
+                        acc[pos] = mfma_bf16x6(a, b4[d], acc[pos]);
+                    }
                 }
             }
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bcur[p] = bnext[p];
         }
         const int ch = 16 * ct + li;
         const float sc = g.sc4[ch], sh = g.sh4[ch];

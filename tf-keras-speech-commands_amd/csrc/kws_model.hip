@@ -374,10 +374,10 @@ static __bf16 *fused_head_plane(CnnWs &w, int p) { return reinterpret_cast<__bf1
 static int split_weights_fused(const kws_model *m, const float *params, CnnWs &w, hipStream_t s)
 {
     FragDescs all{};
-    all.d[0] = FragDesc{params + m->o_k[2], {w.wsp[0][3], w.wsp[0][4], w.wsp[0][5]}, 9, kFuC2, kFuC3, kFuC3 / 16};
-    all.d[1] = FragDesc{params + m->o_k[3], {w.wsp[1][3], w.wsp[1][4], w.wsp[1][5]}, 9, kFuC3, kFuC4, kFuC4 / 16};
-    all.d[2] = FragDesc{params + m->o_dk, {w.wsp[2][3], w.wsp[2][4], w.wsp[2][5]}, kFuH4 * kFuW4, kFuC4, kFuD, kFuD / 16};
-    all.d[3] = FragDesc{params + m->o_hk, {fused_head_plane(w, 0), fused_head_plane(w, 1), fused_head_plane(w, 2)}, 1, kFuD, m->C, kFuHeadCols / 16};
+    all.d[0] = FragDesc{params + m->o_k[2], {w.wsp[0][3], w.wsp[0][4], w.wsp[0][5]}, 9, kFuC2, kFuC3, kFuC3 / 16, 0};
+    all.d[1] = FragDesc{params + m->o_k[3], {w.wsp[1][3], w.wsp[1][4], w.wsp[1][5]}, 9, kFuC3, kFuC4, kFuC4 / 16, 1};
+    all.d[2] = FragDesc{params + m->o_dk, {w.wsp[2][3], w.wsp[2][4], w.wsp[2][5]}, kFuH4 * kFuW4, kFuC4, kFuD, kFuD / 16, 0};
+    all.d[3] = FragDesc{params + m->o_hk, {fused_head_plane(w, 0), fused_head_plane(w, 1), fused_head_plane(w, 2)}, 1, kFuD, m->C, kFuHeadCols / 16, 0};
     KWS_LAUNCH("infer_frag_kernel", infer_frag_kernel, dim3(32, 4), dim3(256), 0, s, all);
     return KWS_OK;
 }

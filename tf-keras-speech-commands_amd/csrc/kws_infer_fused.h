@@ -14,9 +14,11 @@
 //     read, 0.061 ms; every wave re-split every fragment).  Rows are 128 B (32 floats / 64 bf16) without padding; the 16-byte unit u of
 //     row (pixel, clip) sits at u ^ ((clip >> 1) & 7), which makes the ds_read_b128 lane groups {0-3,12-15,20-27}, ... conflict-free;
 //   * the weights never touch LDS: infer_frag_kernel lays every (layer, k-step, column tile, plane) out as the 64 x 16 B a wave loads
-//     with one coalesced instruction (768 KB in all, L2-resident), loaded one k-step ahead;
-//   * eight waves: a wave owns one 16-channel column tile of conv4 / Dense for all 12 positions (conv3: one column tile x 6 positions),
-//     so a block reads every weight fragment exactly once; two waves per SIMD let one wave's splitting run under the other's MFMAs.
+//     with one coalesced instruction (768 KB in all, L2-resident), loaded two k-steps ahead;
+//   * sixteen waves (four per SIMD, 94 registers): a wave owns one 16-channel column tile of conv4 for 6 of the 12 positions = one pooled
+//     row (conv3: one column tile x 3 positions), so a block reads every weight fragment twice (conv3: four times) from L2 -- 1.5 MB per
+//     block; with eight waves and every fragment read once the dependent read -> product chains of two waves per SIMD were the limit
+//     (0.045 against 0.041 ms).
 #pragma once
 
 namespace kws {
@@ -32,7 +34,8 @@ constexpr int kFuRS4 = kFuFlat + 8, kFuRSD = kFuD + 8;         // row strides in
 constexpr int kFuA2 = kFuH2 * kFuW2 * kFuClips * kFuC2;         // floats: a2 [pixel][clip][32], swizzled units, 71 680 B
 constexpr int kFuA3P = kFuH3 * kFuW3 * kFuClips * kFuC3;        // bf16 per plane of a3 [position][clip][64], swizzled units
 constexpr int kFuLdsBytes = 4 * kFuA2 + 3 * 2 * kFuA3P;         // 145 408 B
-constexpr int kFuThreads = 512;
+constexpr int kFuThreads = 1024;                // 16 waves: 4 per SIMD (108 registers)
+constexpr int kFuWaves = kFuThreads / 64, kFuPG = kFuWaves / 8;   // position groups of conv4 (conv3: twice as many)
 static_assert(kFuClips * (kFuRS4 + kFuRSD + kFuHeadCols + 2) <= kFuA2, "the tail of the chain lives in a2's region");
 
 // fragment-major weight planes: element ((ks * NCT + ct) * 64 + lane) * 8 + j of plane p = plane p of W[k(ks, lane >> 4, j)][16 ct + (lane & 15)],
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(kFuThreads, 1) void infer_tail_kernel(FusedTailArgs
     const int sw = (li >> 1) & 7;                                               // this lane's row (clip li) keeps unit u at u ^ sw
 
     // conv3's first weight fragments are on their way while a2 is staged
+    constexpr int NP3 = 12 / (kFuWaves / 4), NP4 = 12 / kFuPG;                   // positions per wave in conv3 / conv4
     const int ct3 = wave & 3, half3 = wave >> 2;
     bf16x8 b3[3][3];
     fu_load_b(g.f3, ct3, lane, b3[0]);
@@ -121,9 +125,9 @@ __global__ __launch_bounds__(kFuThreads, 1) void infer_tail_kernel(FusedTailArgs
 
     // ---- conv3: wave = (column tile ct of 4, half of the 12 positions); A = fp32 rows split in registers ----
     {
-        f32x4 acc[6];
+        f32x4 acc[NP3];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NP3; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int o0 = 4 * (lq ^ sw), o1 = 4 * ((lq + 4) ^ sw);                  // the lane's two units of the 32-channel step
 #pragma unroll 1
         for (int tap3 = 0; tap3 < 9; tap3 += 3) {                               // runtime loop: one kernel row per trip, its three taps unrolled
@@ -133,8 +137,8 @@ __global__ __launch_bounds__(kFuThreads, 1) void infer_tail_kernel(FusedTailArgs
                 if (tap + 2 < 9) fu_load_b(g.f3, (tap + 2) * 4 + ct3, lane, b3[(d + 2) % 3]);     // two k-steps ahead
                 const int kh = tap3 / 3, kw = d;
 #pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const int pos = 6 * half3 + q, oh = pos / kFuW3, ow = pos - oh * kFuW3;
+                for (int q = 0; q < NP3; ++q) {
+                    const int pos = NP3 * half3 + q, oh = pos / kFuW3, ow = pos - oh * kFuW3;
                     const int ih = 2 * oh + kh - 1, iw = 2 * ow + kw - 1;
                     if (ih >= 0 && ih < kFuH2 && iw >= 0 && iw < kFuW2) {       // wave-uniform: the padding taps of this position are skipped
                         const float *row = A2 + ((ih * kFuW2 + iw) * kFuClips + li) * kFuC2;
@@ -150,8 +154,8 @@ __global__ __launch_bounds__(kFuThreads, 1) void infer_tail_kernel(FusedTailArgs
         const int ch = 16 * ct3 + li;
         const float sc = g.sc3[ch], sh = g.sh3[ch];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int pos = 6 * half3 + q;
+        for (int q = 0; q < NP3; ++q) {
+            const int pos = NP3 * half3 + q;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int clip = 4 * lq + r;
@@ -165,16 +169,17 @@ __global__ __launch_bounds__(kFuThreads, 1) void infer_tail_kernel(FusedTailArgs
         }
     }
     bf16x8 b4[3][3];                                                            // conv4's weights: a ring of three k-steps
-    fu_load_b(g.f4, wave, lane, b4[0]);
-    fu_load_b(g.f4, 8 + wave, lane, b4[1]);
+    const int ct4 = wave & 7, pg4 = wave >> 3;
+    fu_load_b(g.f4, ct4, lane, b4[0]);
+    fu_load_b(g.f4, 8 + ct4, lane, b4[1]);
     __syncthreads();
 
     // ---- conv4 (activation='relu') -> BN -> ReLU6 -> 2 x 2 max-pool: wave = column tile (8 of 16 channels), all 12 positions; A = bf16 planes ----
     {
-        const int ct = wave;
-        f32x4 acc[12];
+        const int ct = ct4;
+        f32x4 acc[NP4];
 #pragma unroll
-        for (int q = 0; q < 12; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < NP4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int ks3 = 0; ks3 < 18; ks3 += 3) {
 #pragma unroll
@@ -184,23 +189,25 @@ __global__ __launch_bounds__(kFuThreads, 1) void infer_tail_kernel(FusedTailArgs
                 const int tap = ks >> 1, chunk = ks & 1, kh = tap / 3, kw = tap - kh * 3;
                 const int uo = ((4 * chunk + lq) ^ sw) * 8;
 #pragma unroll
-                for (int pos = 0; pos < 12; ++pos) {
-                    const int oh = pos / kFuW3, ow = pos - oh * kFuW3;
+                for (int q = 0; q < NP4; ++q) {
+                    const int pos = NP4 * pg4 + q, oh = pos / kFuW3, ow = pos - oh * kFuW3;
                     const int ih = oh + kh - 1, iw = ow + kw - 1;
                     if (ih >= 0 && ih < kFuH3 && iw >= 0 && iw < kFuW3) {
                         const __bf16 *row = A3 + ((ih * kFuW3 + iw) * kFuClips + li) * kFuC3 + uo;
                         bf16x8 a[3];
 #pragma unroll
                         for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(row + p * kFuA3P);
-                        acc[pos] = mfma_bf16x6(a, b4[d], acc[pos]);
+                        acc[q] = mfma_bf16x6(a, b4[d], acc[q]);
                     }
                 }
             }
         }
+        // relu -> BN -> ReLU6, then the 2 x 2 maximum: a position group of 6 is two map rows = one pooled row
+        static_assert(NP4 == 12 || NP4 == 6, "a wave holds whole pooling windows");
         const int ch = 16 * ct + li;
         const float sc = g.sc4[ch], sh = g.sh4[ch];
 #pragma unroll
-        for (int ph = 0; ph < kFuH4; ++ph)
+        for (int ph = 0; ph < NP4 / 6; ++ph)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float best = 0.f;                                                // ReLU6 outputs are >= 0
@@ -208,16 +215,16 @@ __global__ __launch_bounds__(kFuThreads, 1) void infer_tail_kernel(FusedTailArgs
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) {
-                        const int pos = (2 * ph + dy) * kFuW3 + dx;              // pooled column 0 = columns 0, 1 (column 2 is dropped: 'valid')
-                        best = fmaxf(best, relu6f(fmaf(fmaxf(acc[pos][r], 0.f), sc, sh)));
+                        const int q = (2 * ph + dy) * kFuW3 + dx;                // pooled column 0 = columns 0, 1 (column 2 is dropped: 'valid')
+                        best = fmaxf(best, relu6f(fmaf(fmaxf(acc[q][r], 0.f), sc, sh)));
                     }
-                A4[(4 * lq + r) * kFuRS4 + ph * kFuW4 * kFuC4 + ch] = best;      // Flatten is (h, w, c)
+                A4[(4 * lq + r) * kFuRS4 + ((NP4 == 6 ? pg4 : ph) * kFuW4) * kFuC4 + ch] = best;      // Flatten is (h, w, c)
             }
     }
     __syncthreads();
 
-    // ---- Dense(128) + ReLU6: wave = column tile ----
-    {
+    // ---- Dense(128) + ReLU6: waves 0..7 = column tiles ----
+    if (wave < kFuD / 16) {
         const int ct = wave;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         bf16x8 bcur[3], bnext[3];

@@ -79,14 +79,36 @@ def test_short_and_long_goldens(torch, feat, golden):
 
 
 def test_tone_high_dynamic_range(torch, feat, golden):
-    """A pure tone has ~120 dB between the tone bin and the quantisation floor; an fp32 FFT (the precision the
-    reference's own numpy>=2 float32 path has, SURVEY 7 'dtype of the Python path') cannot resolve the floor bands
-    to 1e-3.  c0 (log energy) and the bands that carry the tone must still match tightly."""
+    """A pure 1 kHz tone at half scale: one band carries the tone, its two neighbours sit 95-110 dB below it (level -22 .. -25 in log
+    power), three more 110-130 dB below, the rest at the eps clip.  The fp32 transform (the precision the reference's own numpy >= 2
+    float32 path has, SURVEY 7 'dtype of the Python path') resolves all of that: c0 (log energy) within 2e-4 like every other clip, every
+    coefficient within 5e-3 (measured 1.8e-3; round 2 accepted 0.5), and -- in the BAND domain, where an error can be priced against the
+    band's own level -- every band down to 108 dB below the tone within 2.5e-3 of the float64 reference (measured 1.3e-3), the clipped
+    bands exactly at log(eps)."""
+    fo = _oracle()
     t = golden["syn_tone_audio"].astype(np.float32)
-    got = feat(torch.from_numpy(t).cuda()[None])[0].cpu().numpy()
+    got = feat(torch.from_numpy(t).cuda()[None])[0].cpu().numpy().astype(np.float64)
     want = golden["refpy_mel_syn_tone"]
     np.testing.assert_allclose(got[:, 0], want[:, 0], atol=ATOL, rtol=0)
-    np.testing.assert_allclose(got, want, atol=0.5, rtol=0)
+    np.testing.assert_allclose(got, want, atol=5e-3, rtol=0)
+    # band domain: the ortho DCT-II is orthogonal, and c0 (overwritten by the log energy) only carries a per-frame constant over the bands,
+    # so the band logs are known up to that constant; it is fixed on the band that carries the tone
+    N = 20
+    n = np.arange(N)
+    D = np.cos(np.pi * (n[None, :] + 0.5) * n[:, None] / N) * np.where(n[:, None] == 0, np.sqrt(1.0 / N), np.sqrt(2.0 / N))     # D[k][band]
+
+    def bands(c):
+        c = c.copy()
+        c[:, 0] = 0.0
+        return c @ D
+    level = np.log(np.clip(fo.power_spec(t.astype(np.float64), 1024, 512, 1024) @ fo.bank().T, 2.220446049250313e-16, None))    # absolute band logs
+    delta = bands(got) - bands(want)
+    delta -= delta[np.arange(delta.shape[0]), level.argmax(1)][:, None]
+    rel = level - level.max(1, keepdims=True)
+    resolved = rel >= -25.0                                # 108 dB below the tone
+    assert resolved.sum() == 3 * level.shape[0]            # the tone's band and its two neighbours, in every frame
+    assert np.abs(delta[resolved]).max() < 2.5e-3
+    assert np.abs(delta).max() < 5e-3
 
 
 @pytest.mark.parametrize("name", NAMES[:2])

@@ -149,3 +149,53 @@ def test_parallel_helper_single_process():
     g = torch.ones(8)
     dp.sync_grads(g)
     assert torch.equal(g, torch.ones(8))
+
+
+def _write_wav(path, data, rate, width=2):
+    import wave
+    w = wave.open(str(path), "wb")
+    w.setnchannels(data.shape[1] if data.ndim == 2 else 1)
+    w.setsampwidth(width)
+    w.setframerate(rate)
+    w.writeframes(data.tobytes())
+    w.close()
+
+
+def test_load_wav_follows_the_librosa_load_contract(tmp_path):
+    """common/data_utils.py:93 loads with librosa.load(sr=16000, mono=True): float32 in [-1, 1), channels averaged, other sample rates
+    resampled to 16 kHz (length ceil(n sr / rate)).  host only: no GPU involved."""
+    from common.data_utils import load_wav
+    rng = np.random.default_rng(0)
+    # 16 kHz PCM16 mono: exact int16 / 32768
+    pcm = rng.integers(-20000, 20000, 16000).astype("<i2")
+    _write_wav(tmp_path / "a.wav", pcm, 16000)
+    a = load_wav(str(tmp_path / "a.wav"))
+    assert a.dtype == np.float32 and a.shape == (16000,)
+    np.testing.assert_array_equal(a, pcm.astype(np.float32) / 32768.0)
+    # stereo: the mean of the channels
+    st = rng.integers(-20000, 20000, (8000, 2)).astype("<i2")
+    _write_wav(tmp_path / "s.wav", st, 16000)
+    np.testing.assert_allclose(load_wav(str(tmp_path / "s.wav")), st.astype(np.float32).mean(1) / 32768.0, atol=1e-7)
+    # 44.1 kHz and 8 kHz tones come back at 16 kHz with the right length, frequency and amplitude
+    for rate, f0 in ((44100, 1000.0), (8000, 440.0), (48000, 3000.0)):
+        n = rate                                           # one second
+        t = np.arange(n) / float(rate)
+        tone = np.round(0.5 * np.sin(2 * np.pi * f0 * t) * 32767).astype("<i2")
+        _write_wav(tmp_path / ("t%d.wav" % rate), tone, rate)
+        got = load_wav(str(tmp_path / ("t%d.wav" % rate)))
+        assert got.dtype == np.float32 and got.shape == (16000,)
+        want = 0.5 * np.sin(2 * np.pi * f0 * np.arange(16000) / 16000.0)
+        mid = slice(200, -200)                             # away from the filter's edge transients
+        assert np.abs(got[mid] - want[mid]).max() < 2e-3, (rate, np.abs(got[mid] - want[mid]).max())
+    # content above the new Nyquist frequency is removed, not aliased
+    t = np.arange(44100) / 44100.0
+    hi = np.round(0.5 * np.sin(2 * np.pi * 12000.0 * t) * 32767).astype("<i2")
+    _write_wav(tmp_path / "hi.wav", hi, 44100)
+    assert np.abs(load_wav(str(tmp_path / "hi.wav"))[200:-200]).max() < 1e-3
+    # 8-bit and 32-bit PCM
+    u8 = rng.integers(0, 256, 4000).astype(np.uint8)
+    _write_wav(tmp_path / "u8.wav", u8, 16000, width=1)
+    np.testing.assert_allclose(load_wav(str(tmp_path / "u8.wav")), (u8.astype(np.float32) - 128.0) / 128.0)
+    i32 = rng.integers(-2 ** 30, 2 ** 30, 4000).astype("<i4")
+    _write_wav(tmp_path / "i32.wav", i32, 16000, width=4)
+    np.testing.assert_allclose(load_wav(str(tmp_path / "i32.wav")), i32 / 2147483648.0, atol=1e-7)

@@ -95,21 +95,34 @@ def audio_to_feature(audio_data):
 
 
 def load_wav(audio_path):
-    """PCM16 wav -> float32 mono at pr.sample_rate (librosa.load(sr=..., mono=True) contract, no resampler)"""
+    """wav file -> float32 mono at pr.sample_rate: the contract of librosa.load(path, sr=pr.sample_rate, mono=True)
+    (common/data_utils.py:93): channels averaged, 8 / 16 / 32-bit PCM scaled to [-1, 1), and a file at another rate RESAMPLED to
+    pr.sample_rate.  librosa resamples with a band-limited sinc kernel (soxr_hq / kaiser_best depending on its version, unpinned in the
+    reference); here it is scipy's polyphase FIR with a Kaiser window (resample_poly, beta 14, ~-90 dB stop band): the same length
+    (ceil(n * sr / rate)) and the same samples to ~1e-3 of full scale inside the pass band, not bit-equal -- Speech Commands itself is
+    16 kHz and never takes this branch."""
     w = wave.open(audio_path, 'rb')
     try:
         nch, width, rate, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
         raw = w.readframes(n)
     finally:
         w.close()
-    if width != 2:
-        raise ValueError('%s: only 16-bit PCM is supported (sample width %d)' % (audio_path, width))
-    if rate != pr.sample_rate:
-        raise ValueError('%s: sample rate %d != params sample_rate %d (resampling is out of scope; convert '
-                         'the file first)' % (audio_path, rate, pr.sample_rate))
-    audio = np.frombuffer(raw, dtype='<i2').astype(np.float32) / 32768.0
+    if width == 2:
+        audio = np.frombuffer(raw, dtype='<i2').astype(np.float32) / 32768.0
+    elif width == 1:
+        audio = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    elif width == 4:
+        audio = (np.frombuffer(raw, dtype='<i4').astype(np.float64) / 2147483648.0).astype(np.float32)
+    else:
+        raise ValueError('%s: unsupported PCM sample width %d' % (audio_path, width))
     if nch > 1:
         audio = audio.reshape(-1, nch).mean(axis=1).astype(np.float32)
+    if rate != pr.sample_rate and len(audio):
+        from math import gcd
+        from scipy.signal import resample_poly
+        g = gcd(int(pr.sample_rate), int(rate))
+        want = int(np.ceil(len(audio) * pr.sample_rate / float(rate)))
+        audio = resample_poly(audio.astype(np.float64), pr.sample_rate // g, rate // g, window=('kaiser', 14.0))[:want].astype(np.float32)
     return audio
 
 

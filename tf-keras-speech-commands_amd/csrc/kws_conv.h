@@ -190,7 +190,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
 //   MODE_DGRAD rows = input pixels of a STRIDE-1 layer, source (y + pt - kh, x + pl - kw) in the output map, CR = the
 //              layer's output channels, CO = its input channels, B = original-order planes
 // ---------------------------------------------------------------------------------------------------------------
-struct SplitDesc { const float *w; __bf16 *o[3], *t[3]; int taps, ci, co; };
+// frag: 0 = t planes transposed per tap (above); 1 / 2 = t planes FRAGMENT-MAJOR for the clip-group kernels (kws_infer_fused.h,
+// kws_conv_group.h): element ((ks * (co / 16) + col / 16) * 64 + lane) * 8 + j with k-step ks = tap * (ci / 32) + c / 32, lane = col % 16 +
+// 16 lq, and the channel c % 32 at (lq, j) = (unit % 4, c % 4 + 4 (unit / 4)), unit = (c % 32) / 4, for frag = 1 (A operand = fp32 rows) or
+// (c % 32 / 8, c % 8) for frag = 2 (A operand = bf16 planes)
+struct SplitDesc { const float *w; __bf16 *o[3], *t[3]; int taps, ci, co, frag; };
 struct SplitDescs { SplitDesc d[4]; };
 
 // one x-slice (bx of nbx) of descriptor d
@@ -203,7 +207,12 @@ __device__ __forceinline__ void weight_split_slice(const SplitDesc &d, int bx, i
         const float r1 = v - (float)h;
         const __bf16 m = (__bf16)r1, l = (__bf16)(r1 - (float)m);
         const int tap = i / per, r = i - tap * per, ci = r / d.co, co = r - ci * d.co;
-        const int t = tap * per + co * d.ci + ci;
+        int t = tap * per + co * d.ci + ci;
+        if (d.frag) {
+            const int ks = tap * (d.ci / 32) + ci / 32, c32 = ci & 31;
+            const int lq = d.frag == 1 ? (c32 >> 2) & 3 : c32 >> 3, j = d.frag == 1 ? (c32 & 3) + 4 * (c32 >> 4) : c32 & 7;
+            t = ((ks * (d.co / 16) + co / 16) * 64 + (co & 15) + 16 * lq) * 8 + j;
+        }
         d.o[0][i] = h; d.o[1][i] = m; d.o[2][i] = l;
         d.t[0][t] = h; d.t[1][t] = m; d.t[2][t] = l;
     }

@@ -1,0 +1,180 @@
+// csrc/kws_conv_group.h -- TRAINING forward of conv3 and conv4 of simple_cnn (classifier/models/cnn.py:44-60) at the default geometry in
+// the clip-group form of kws_infer_fused.h: a block owns 16 clips, the MFMA row tile of an output position is the 16 clips at that
+// position (row = clip), so the (position, tap) pairs that fall into the 'same' padding are skipped as whole tiles (38 of 108), the A
+// fragment of (position, tap) is the 16 clips' channel vectors at one input pixel in LDS, and the weights come fragment-major straight
+// from L2 (weight_split_slice, frag forms).  Training-mode BatchNormalization needs the batch statistics of every layer before the next
+// one starts, so the layers stay separate launches; each writes its pre-activation tensor and the per-block partial sums (sum, sum of
+// squares per channel, double) its BatchNorm finalize kernel reduces -- the contract of conv_bf16_kernel<.., STATS>, which these replace:
+// 0.051 + 0.048 ms of a forward chain that nothing overlaps (rocprofv3 timeline).
+//   conv3: a2 (B, 7, 5, 32) fp32 -> z3 (B, 4, 3, 64); A = fp32 rows split into h / m / l in registers (kws_infer_fused.h: fu_split)
+//   conv4: z3 -> a3 = relu6(BN3(z3)) formed and split ONCE per element while it is staged (a3 is never written to memory) -> z4 =
+//          relu(conv4(a3)) (B, 4, 3, 128) (Conv2D(activation='relu'), cnn.py:55); A = three bf16 planes, one ds_read_b128 each
+#pragma once
+
+namespace kws {
+
+constexpr int kGrThreads = 1024, kGrWaves = kGrThreads / 64;
+
+// partial[(which * C + ch) * stride + blockIdx.x] = this block's sum / sum of squares of channel ch; `red` = 2 * G * C doubles of LDS
+template <int C, int G>
+__device__ __forceinline__ void group_stats(float s, float ss, int ch, int grp, int lq, double *red, double *__restrict__ partial, int stride)
+{
+    double a = (double)s, q = (double)ss;
+    a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+    if (lq == 0) { red[(grp * 2 + 0) * C + ch] = a; red[(grp * 2 + 1) * C + ch] = q; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += kGrThreads) {
+        const int which = i / C, n = i - which * C;
+        double t = 0.0;
+#pragma unroll
+        for (int g2 = 0; g2 < G; ++g2) t += red[(g2 * 2 + which) * C + n];          // fixed order: deterministic
+        partial[((long)which * C + n) * stride + blockIdx.x] = t;
+    }
+}
+
+struct GroupConv3Args { const float *a2; const __bf16 *f3[3]; float *z3; double *partial; int stride, B; };
+
+__global__ __launch_bounds__(kGrThreads, 1) void conv3_group_fwd_kernel(GroupConv3Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) float gr_lds[];
+    float *A2 = gr_lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lq = lane >> 4;
+    const int b0 = blockIdx.x * kFuClips;
+    const int sw = (li >> 1) & 7;
+    constexpr int NP = 12 / (kGrWaves / 4);                                     // positions per wave: 3
+    const int ct = wave & 3, grp = wave >> 2;
+    bf16x8 b3[3][3];
+    fu_load_b(g.f3, ct, lane, b3[0]);
+    fu_load_b(g.f3, 4 + ct, lane, b3[1]);
+    {
+        constexpr int PER = kFuH2 * kFuW2 * kFuC2 / 4;
+        for (int i = tid; i < kFuClips * PER; i += kGrThreads) {
+            const int c = i / PER, r = i - c * PER, px = r >> 3, u = r & 7;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b0 + c < g.B) v = *reinterpret_cast<const f32x4 *>(g.a2 + ((long)(b0 + c) * PER + r) * 4);
+            *reinterpret_cast<f32x4 *>(A2 + ((px * kFuClips + c) * 8 + (u ^ ((c >> 1) & 7))) * 4) = v;
+        }
+    }
+    __syncthreads();
+    f32x4 acc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int o0 = 4 * (lq ^ sw), o1 = 4 * ((lq + 4) ^ sw);
+#pragma unroll 1
+    for (int tap3 = 0; tap3 < 9; tap3 += 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int tap = tap3 + d;
+            if (tap + 2 < 9) fu_load_b(g.f3, (tap + 2) * 4 + ct, lane, b3[(d + 2) % 3]);
+            const int kh = tap3 / 3, kw = d;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int pos = NP * grp + q, oh = pos / kFuW3, ow = pos - oh * kFuW3;
+                const int ih = 2 * oh + kh - 1, iw = 2 * ow + kw - 1;
+                if (ih >= 0 && ih < kFuH2 && iw >= 0 && iw < kFuW2) {
+                    const float *row = A2 + ((ih * kFuW2 + iw) * kFuClips + li) * kFuC2;
+                    bf16x8 a[3];
+                    fu_split(*reinterpret_cast<const f32x4 *>(row + o0), *reinterpret_cast<const f32x4 *>(row + o1), a);
+                    acc[q] = mfma_bf16x6(a, b3[d], acc[q]);
+                }
+            }
+        }
+    }
+    // z3 and the BatchNorm partial sums (rows of clips past the batch are zero: they add nothing)
+    const int ch = 16 * ct + li;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pos = NP * grp + q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int clip = 4 * lq + r;
+            const float v = acc[q][r];
+            if (b0 + clip < g.B) g.z3[((long)(b0 + clip) * (kFuH3 * kFuW3) + pos) * kFuC3 + ch] = v;
+            s += v; ss = fmaf(v, v, ss);
+        }
+    }
+    __syncthreads();                                                            // a2's region becomes the reduction scratch
+    group_stats<kFuC3, kGrWaves / 4>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride);
+}
+
+struct GroupConv4Args { const float *z3, *sc3, *sh3; const __bf16 *f4[3]; float *z4; double *partial; int stride, B; };
+
+__global__ __launch_bounds__(kGrThreads, 1) void conv4_group_fwd_kernel(GroupConv4Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) float gr_lds[];
+    __bf16 *A3 = reinterpret_cast<__bf16 *>(gr_lds);                            // three planes of kFuA3P, [position][clip][8 units of 8], swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lq = lane >> 4;
+    const int b0 = blockIdx.x * kFuClips;
+    const int sw = (li >> 1) & 7;
+    constexpr int NP = 12 / (kGrWaves / 8);                                     // positions per wave: 6
+    const int ct = wave & 7, grp = wave >> 3;
+    bf16x8 b4[3][3];
+    fu_load_b(g.f4, ct, lane, b4[0]);
+    fu_load_b(g.f4, 8 + ct, lane, b4[1]);
+    // a3 = relu6(BN3(z3)), split once per element, into the planes
+    {
+        constexpr int PER = kFuH3 * kFuW3 * kFuC3 / 4;                          // float4 per clip: 192
+        for (int i = tid; i < kFuClips * PER; i += kGrThreads) {
+            const int c = i / PER, r = i - c * PER, pos = r >> 4, u4 = r & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b0 + c < g.B) {
+                const f32x4 z = *reinterpret_cast<const f32x4 *>(g.z3 + ((long)(b0 + c) * PER + r) * 4);
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(g.sc3 + 4 * u4), sh = *reinterpret_cast<const f32x4 *>(g.sh3 + 4 * u4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = relu6f(fmaf(z[e], sc[e], sh[e]));
+            }
+            bf16x4 h, m, l;
+            split_bf16(v, h, m, l);
+            const int e0 = ((pos * kFuClips + c) * 8 + ((u4 >> 1) ^ ((c >> 1) & 7))) * 8 + (u4 & 1) * 4;
+            *reinterpret_cast<bf16x4 *>(A3 + e0) = h;
+            *reinterpret_cast<bf16x4 *>(A3 + kFuA3P + e0) = m;
+            *reinterpret_cast<bf16x4 *>(A3 + 2 * kFuA3P + e0) = l;
+        }
+    }
+    __syncthreads();
+    f32x4 acc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks3 = 0; ks3 < 18; ks3 += 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int ks = ks3 + d;
+            if (ks + 2 < 18) fu_load_b(g.f4, (long)(ks + 2) * 8 + ct, lane, b4[(d + 2) % 3]);
+            const int tap = ks >> 1, chunk = ks & 1, kh = tap / 3, kw = tap - kh * 3;
+            const int uo = ((4 * chunk + lq) ^ sw) * 8;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int pos = NP * grp + q, oh = pos / kFuW3, ow = pos - oh * kFuW3;
+                const int ih = oh + kh - 1, iw = ow + kw - 1;
+                if (ih >= 0 && ih < kFuH3 && iw >= 0 && iw < kFuW3) {
+                    const __bf16 *row = A3 + ((ih * kFuW3 + iw) * kFuClips + li) * kFuC3 + uo;
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(row + p * kFuA3P);
+                    acc[q] = mfma_bf16x6(a, b4[d], acc[q]);
+                }
+            }
+        }
+    }
+    // z4 = relu(conv) (the layer's own activation, in front of its BatchNormalization) and the partial sums
+    const int ch = 16 * ct + li;
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pos = NP * grp + q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int clip = 4 * lq + r;
+            const float v = fmaxf(acc[q][r], 0.f);
+            if (b0 + clip < g.B) g.z4[((long)(b0 + clip) * (kFuH3 * kFuW3) + pos) * kFuC4 + ch] = v;
+            s += v; ss = fmaf(v, v, ss);
+        }
+    }
+    __syncthreads();
+    group_stats<kFuC4, kGrWaves / 8>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride);
+}
+
+}  // namespace kws

@@ -18,6 +18,7 @@
 #include "kws_lite.h"
 #include "kws_lite_f16.h"
 #include "kws_infer_fused.h"
+#include "kws_conv_group.h"
 
 using namespace kws;
 
@@ -338,27 +339,48 @@ int launch_bf16(const char *what, const float *src, __bf16 *const planes[6], con
 }
 
 // h/m/l bf16 planes of the three GEMM weight tensors, once per step (one launch)
-static SplitDescs split_descs(const kws_model *m, const float *params, CnnWs &w)
+// training at the default geometry: conv3 / conv4 forward run as clip-group kernels (kws_conv_group.h), whose weights are fragment-major
+static bool group_fwd_ok(const kws_model *m)
+{
+    const CnnDims &d = m->d;
+    return m->kind == KWS_SIMPLE_CNN && d.H2 == kFuH2 && d.W2 == kFuW2 && d.H3 == kFuH3 && d.W3 == kFuW3;
+}
+static SplitDescs split_descs(const kws_model *m, const float *params, CnnWs &w, bool group_fwd = false)
 {
     SplitDescs all{};
     const float *src[3] = {params + m->o_k[2], params + m->o_k[3], params + m->o_dk};
     const int taps[3] = {9, 9, m->d.H4 * m->d.W4}, ci[3] = {32, 64, 128}, co[3] = {64, 128, 128};
+    const int frag[3] = {group_fwd ? 1 : 0, group_fwd ? 2 : 0, 0};
     for (int t = 0; t < 3; ++t)
-        all.d[t] = SplitDesc{src[t], {w.wsp[t][0], w.wsp[t][1], w.wsp[t][2]}, {w.wsp[t][3], w.wsp[t][4], w.wsp[t][5]}, taps[t], ci[t], co[t]};
+        all.d[t] = SplitDesc{src[t], {w.wsp[t][0], w.wsp[t][1], w.wsp[t][2]}, {w.wsp[t][3], w.wsp[t][4], w.wsp[t][5]}, taps[t], ci[t], co[t], frag[t]};
     all.d[3] = all.d[2];
     return all;
 }
 
-static int split_weights(const kws_model *m, const float *params, CnnWs &w, hipStream_t s)
+static int split_weights(const kws_model *m, const float *params, CnnWs &w, hipStream_t s, bool group_fwd = false)
 {
-    SplitDescs all{};
-    const float *src[3] = {params + m->o_k[2], params + m->o_k[3], params + m->o_dk};
-    const int taps[3] = {9, 9, m->d.H4 * m->d.W4}, ci[3] = {32, 64, 128}, co[3] = {64, 128, 128};
-    for (int t = 0; t < 3; ++t)
-        all.d[t] = SplitDesc{src[t], {w.wsp[t][0], w.wsp[t][1], w.wsp[t][2]}, {w.wsp[t][3], w.wsp[t][4], w.wsp[t][5]}, taps[t], ci[t], co[t]};
-    all.d[3] = all.d[2];
+    const SplitDescs all = split_descs(m, params, w, group_fwd);
     KWS_LAUNCH("weight_split_kernel", weight_split_kernel, dim3(64, 3), dim3(256), 0, s, all);
     return KWS_OK;
+}
+static int launch_group_conv3(const kws_model *m, int B, CnnWs &w, hipStream_t s)
+{
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv3_group_fwd_kernel), 4 * kFuA2)) return rc;
+    GroupConv3Args a{};
+    a.a2 = w.a[1]; a.z3 = w.z[2]; a.partial = w.partial; a.stride = kStatStride; a.B = B;
+    for (int p = 0; p < 3; ++p) a.f3[p] = w.wsp[0][3 + p];
+    KWS_LAUNCH("conv_group_fwd<32,64>", conv3_group_fwd_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(4 * kFuA2), s, a);
+    return (int)blocks_for(B, kFuClips);
+}
+static int launch_group_conv4(const kws_model *m, int B, CnnWs &w, hipStream_t s)
+{
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv4_group_fwd_kernel), 6 * kFuA3P)) return rc;
+    GroupConv4Args a{};
+    const BnCoef k3 = coef_of(w.coef[2], 64);
+    a.z3 = w.z[2]; a.sc3 = k3.scale; a.sh3 = k3.shift; a.z4 = w.z[3]; a.partial = w.partial; a.stride = kStatStride; a.B = B;
+    for (int p = 0; p < 3; ++p) a.f4[p] = w.wsp[1][3 + p];
+    KWS_LAUNCH("conv_group_fwd<64,128>", conv4_group_fwd_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(6 * kFuA3P), s, a);
+    return (int)blocks_for(B, kFuClips);
 }
 
 // Inference of simple_cnn in split precision at the default geometry: everything behind the second pooling stage is ONE kernel
@@ -439,6 +461,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool prepared = !training && m->prepared_for(params, state, w.base, B, matrix_prec(m), infer_prec(m));
     // inference with a caller that takes the head's outputs here: conv3 .. softmax as one kernel (kws_infer_fused.h)
     const bool fused_tail = !training && head_done && fused_tail_ok(m, bf16);
+    // training in split precision at the default geometry: conv3 / conv4 forward as clip-group kernels (needs at most kStatStride blocks)
+    const bool group_fwd = training && bf16 && group_fwd_ok(m) && (long)blocks_for(B, kFuClips) <= kStatStride;
     ModelRes *R = nullptr;       // only the split-on-the-side-stream branch below needs the model's stream / events
     // training in split precision at a geometry the MFMA layer-1 kernels cover: the weight split and the gradient clear ride
     // in the grid of the layer-1 activation kernel -- no side-stream branch, no events
@@ -457,7 +481,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             KWS_HIP_CHECK(hipMemsetAsync(zero_grads, 0, sizeof(float) * (size_t)m->P, s2));
             if (zeroed) *zeroed = true;
         }
-        if (int rc = split_weights(m, params, w, s2)) return rc;
+        if (int rc = split_weights(m, params, w, s2, group_fwd)) return rc;
         KWS_HIP_CHECK(hipEventRecord(R->ev[11], s2));
     } else if (bf16) {
         // inference stays on ONE stream: callers capture it into hipGraphs, and a fork to the library's side stream inside
@@ -491,7 +515,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             }
             L1PrepArgs pa{};
             if (prep_in_stats) {
-                pa.all = split_descs(m, params, w); pa.zero_buf = zero_grads; pa.zero_n = (long)m->P;
+                pa.all = split_descs(m, params, w, group_fwd); pa.zero_buf = zero_grads; pa.zero_n = (long)m->P;
                 pa.nsplit = kPrepSplitBlocks; pa.nzero = kPrepZeroBlocks;
                 KWS_LAUNCH("l1m_act_pool_kernel", l1m_act_pool_moments_kernel<true>, dim3(nbm + kPrepBlocks), dim3(256), smemm, s, feat, kern1, q,
                            params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1, w.a[0], B, d.H0, d.W0, cpw, nbm, pa);
@@ -558,14 +582,20 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         } else if (l == 2) {
             if (bf16 && training && !prep_in_stats) KWS_HIP_CHECK(hipStreamWaitEvent(s, R->ev[11], 0));     // the weight planes are ready
             // the split-precision kernels write the BatchNorm partial sums from their epilogue when training
-            if (bf16) {
+            if (group_fwd) {
+                fused_stat_blocks = launch_group_conv3(m, B, w, s);
+                if (fused_stat_blocks < 0) return fused_stat_blocks;
+            } else if (bf16) {
                 fused_stat_blocks = launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s,
                                                                           training ? w.partial : nullptr);
                 if (fused_stat_blocks < 0) return fused_stat_blocks;
             } else KWS_TRY(launch_gemm<32, 64, MODE_FWD, EPI_NONE>(in, kern, nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s));
         } else {
             // activation='relu', cnn.py:55
-            if (bf16) {
+            if (group_fwd) {
+                fused_stat_blocks = launch_group_conv4(m, B, w, s);          // forms a3 = relu6(BN3(z3)) while staging, like the ABN form below
+                if (fused_stat_blocks < 0) return fused_stat_blocks;
+            } else if (bf16) {
                 // training: a3 = relu6(BN3(z3)) is never written -- conv4 forms it from z3 while it stages its rows, and so does conv4's
                 // weight gradient (conv3 has no pooling, so the activation is a per-element map)
                 fused_stat_blocks = launch_bf16<64, 128, MODE_FWD, EPI_RELU>("conv_bf16_fwd", a3_on_load ? w.z[2] : in, w.wsp[1], nullptr, w.z[3],

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
 // kws_conv_group.h): element ((ks * (co / 16) + col / 16) * 64 + lane) * 8 + j with k-step ks = tap * (ci / 32) + c / 32, lane = col % 16 +
 // 16 lq, and the channel c % 32 at (lq, j) = (unit % 4, c % 4 + 4 (unit / 4)), unit = (c % 32) / 4, for frag = 1 (A operand = fp32 rows) or
 // (c % 32 / 8, c % 8) for frag = 2 (A operand = bf16 planes)
-struct SplitDesc { const float *w; __bf16 *o[3], *t[3]; int taps, ci, co, frag; };
+// ofrag: the o planes fragment-major for the clip-group DATA gradient (reduction over co, columns ci): element ((ks * (ci / 16) + c / 16) * 64 +
+// lane) * 8 + j with ks = tap * (co / 32) + o / 32, lane = c % 16 + 16 ((o % 32) / 8), j = o % 8 for W[tap][c][o]
+struct SplitDesc { const float *w; __bf16 *o[3], *t[3]; int taps, ci, co, frag, ofrag; };
 struct SplitDescs { SplitDesc d[4]; };
 
 // one x-slice (bx of nbx) of descriptor d
@@ -213,7 +215,12 @@ __device__ __forceinline__ void weight_split_slice(const SplitDesc &d, int bx, i
             const int lq = d.frag == 1 ? (c32 >> 2) & 3 : c32 >> 3, j = d.frag == 1 ? (c32 & 3) + 4 * (c32 >> 4) : c32 & 7;
             t = ((ks * (d.co / 16) + co / 16) * 64 + (co & 15) + 16 * lq) * 8 + j;
         }
-        d.o[0][i] = h; d.o[1][i] = m; d.o[2][i] = l;
+        int io = i;
+        if (d.ofrag) {
+            const int ks = tap * (d.co / 32) + co / 32;
+            io = ((ks * (d.ci / 16) + ci / 16) * 64 + (ci & 15) + 16 * ((co & 31) >> 3)) * 8 + (co & 7);
+        }
+        d.o[0][io] = h; d.o[1][io] = m; d.o[2][io] = l;
         d.t[0][t] = h; d.t[1][t] = m; d.t[2][t] = l;
     }
 }

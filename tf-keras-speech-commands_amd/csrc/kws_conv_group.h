@@ -177,4 +177,80 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_fwd_kernel(GroupCon
     group_stats<kFuC4, kGrWaves / 8>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride);
 }
 
+// conv4's DATA gradient in the same form: dz4 arrives as the h / m / l bf16 planes BatchNorm-4's backward wrote ((B, 4, 3, 128) each), so
+// staging is a copy of 16-byte units into [position][clip][16 units], unit u of clip c at u ^ (c & 15) (256-byte rows: that swizzle makes
+// the ds_read_b128 lane groups conflict-free); da3(y, x) = sum over taps of dz4(y + 1 - kh, x + 1 - kw) W[kh][kw]^T, reduced over the 128
+// output channels (36 k-steps), 64 columns.  The epilogue is BatchNorm-3's backward reduction (conv3 has no pooling): g = da3 gated by
+// ReLU6(BN3(z3)), stored, and the per-block sums of g and g xhat -- the contract of conv_bf16_kernel<128, 64, MODE_DGRAD, EPI_BNBWD_GATE6>.
+constexpr int kGrD4P = kFuH3 * kFuW3 * kFuClips * kFuC4;                        // bf16 per plane of the staged dz4
+struct GroupDgrad4Args { const __bf16 *dz[3], *fw[3]; const float *z3, *coef; float *g3; double *partial; int stride, B; };
+
+__global__ __launch_bounds__(kGrThreads, 1) void conv4_group_dgrad_kernel(GroupDgrad4Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) float gr_lds[];
+    __bf16 *D4 = reinterpret_cast<__bf16 *>(gr_lds);                            // three planes of kGrD4P
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lq = lane >> 4;
+    const int b0 = blockIdx.x * kFuClips;
+    constexpr int NP = 12 / (kGrWaves / 4);                                     // positions per wave: 3
+    const int ct = wave & 3, grp = wave >> 2;
+    bf16x8 bw[3][3];
+    fu_load_b(g.fw, ct, lane, bw[0]);
+    fu_load_b(g.fw, 4 + ct, lane, bw[1]);
+    {
+        constexpr int PER = kFuH3 * kFuW3 * kFuC4 / 8;                          // 16-byte units per clip and plane: 192
+        for (int i = tid; i < 3 * kFuClips * PER; i += kGrThreads) {
+            const int p = i / (kFuClips * PER), r0 = i - p * (kFuClips * PER), c = r0 / PER, r = r0 - c * PER, pos = r >> 4, u = r & 15;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (b0 + c < g.B) v = *reinterpret_cast<const bf16x8 *>(g.dz[p] + ((long)(b0 + c) * PER + r) * 8);
+            *reinterpret_cast<bf16x8 *>(D4 + p * kGrD4P + ((pos * kFuClips + c) * 16 + (u ^ (c & 15))) * 8) = v;
+        }
+    }
+    __syncthreads();
+    f32x4 acc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks3 = 0; ks3 < 36; ks3 += 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int ks = ks3 + d;
+            if (ks + 2 < 36) fu_load_b(g.fw, (long)(ks + 2) * 4 + ct, lane, bw[(d + 2) % 3]);
+            const int tap = ks >> 2, chunk = ks & 3, kh = tap / 3, kw = tap - kh * 3;
+            const int uo = ((4 * chunk + lq) ^ li) * 8;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int pos = NP * grp + q, y = pos / kFuW3, x = pos - y * kFuW3;
+                const int sy = y + 1 - kh, sx = x + 1 - kw;
+                if (sy >= 0 && sy < kFuH3 && sx >= 0 && sx < kFuW3) {
+                    const __bf16 *row = D4 + ((sy * kFuW3 + sx) * kFuClips + li) * kFuC4 + uo;
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(row + p * kGrD4P);
+                    acc[q] = mfma_bf16x6(a, bw[d], acc[q]);
+                }
+            }
+        }
+    }
+    const int ch = 16 * ct + li;
+    const float gsc = g.coef[ch], gsh = g.coef[kFuC3 + ch], gmean = g.coef[2 * kFuC3 + ch], ginv = g.coef[3 * kFuC3 + ch];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pos = NP * grp + q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int clip = 4 * lq + r;
+            if (b0 + clip < g.B) {
+                const long e = ((long)(b0 + clip) * (kFuH3 * kFuW3) + pos) * kFuC3 + ch;
+                const float zv = g.z3[e], yv = fmaf(zv, gsc, gsh);
+                const float v = (yv > 0.f && yv < 6.f) ? acc[q][r] : 0.f;
+                g.g3[e] = v;
+                s += v; ss = fmaf(v, (zv - gmean) * ginv, ss);
+            }
+        }
+    }
+    __syncthreads();
+    group_stats<kFuC3, kGrWaves / 4>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride);
+}
+
 }  // namespace kws

@@ -350,9 +350,10 @@ static SplitDescs split_descs(const kws_model *m, const float *params, CnnWs &w,
     SplitDescs all{};
     const float *src[3] = {params + m->o_k[2], params + m->o_k[3], params + m->o_dk};
     const int taps[3] = {9, 9, m->d.H4 * m->d.W4}, ci[3] = {32, 64, 128}, co[3] = {64, 128, 128};
-    const int frag[3] = {group_fwd ? 1 : 0, group_fwd ? 2 : 0, 0};
+    const int frag[3] = {group_fwd ? 1 : 0, group_fwd ? 2 : 0, 0}, ofrag[3] = {0, group_fwd ? 1 : 0, 0};
     for (int t = 0; t < 3; ++t)
-        all.d[t] = SplitDesc{src[t], {w.wsp[t][0], w.wsp[t][1], w.wsp[t][2]}, {w.wsp[t][3], w.wsp[t][4], w.wsp[t][5]}, taps[t], ci[t], co[t], frag[t]};
+        all.d[t] = SplitDesc{src[t], {w.wsp[t][0], w.wsp[t][1], w.wsp[t][2]}, {w.wsp[t][3], w.wsp[t][4], w.wsp[t][5]}, taps[t], ci[t], co[t], frag[t],
+                             ofrag[t]};
     all.d[3] = all.d[2];
     return all;
 }
@@ -370,6 +371,15 @@ static int launch_group_conv3(const kws_model *m, int B, CnnWs &w, hipStream_t s
     a.a2 = w.a[1]; a.z3 = w.z[2]; a.partial = w.partial; a.stride = kStatStride; a.B = B;
     for (int p = 0; p < 3; ++p) a.f3[p] = w.wsp[0][3 + p];
     KWS_LAUNCH("conv_group_fwd<32,64>", conv3_group_fwd_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(4 * kFuA2), s, a);
+    return (int)blocks_for(B, kFuClips);
+}
+static int launch_group_dgrad4(const kws_model *m, int B, CnnWs &w, hipStream_t s)
+{
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv4_group_dgrad_kernel), 6 * kGrD4P)) return rc;
+    GroupDgrad4Args a{};
+    a.z3 = w.z[2]; a.coef = coef_of(w.coef[2], 64).scale; a.g3 = w.gz[2]; a.partial = w.partial; a.stride = kStatStride; a.B = B;
+    for (int p = 0; p < 3; ++p) { a.dz[p] = w.dzp[p]; a.fw[p] = w.wsp[1][p]; }
+    KWS_LAUNCH("conv_group_dgrad<128,64>", conv4_group_dgrad_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(6 * kGrD4P), s, a);
     return (int)blocks_for(B, kFuClips);
 }
 static int launch_group_conv4(const kws_model *m, int B, CnnWs &w, hipStream_t s)
@@ -803,7 +813,11 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             // (the caller's stream does not wait for the conv4 wgrad, and the collective runs under the rest of the backward pass).
             if (comm) KWS_TRY(comm_allreduce_early(comm, grads + m->o_k[3], m->P - m->o_k[3], s2));
             if (bucket_event) KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
-            if (mprec == 1 && blocks_for((long)B * Hs[3] * Ws[3], 64) <= (unsigned)kStatStride) {
+            if (mprec == 1 && group_fwd_ok(m) && (long)blocks_for(B, kFuClips) <= kStatStride) {
+                // the clip-group form (the forward pass prepared the weights for it: same predicate as cnn_forward's group_fwd)
+                fused_bn3_blocks = launch_group_dgrad4(m, B, w, s);
+                if (fused_bn3_blocks < 0) return fused_bn3_blocks;
+            } else if (mprec == 1 && blocks_for((long)B * Hs[3] * Ws[3], 64) <= (unsigned)kStatStride) {
                 // the data gradient's epilogue is BatchNorm 3's backward reduction (conv3 has no pooling): it gates by ReLU6(y3), stores
                 // g in gz[2] and leaves the partial sums of g and g xhat -- no bn_bwd_reduce pass over (z3, da3)
                 const BnCoef k3 = coef_of(w.coef[2], 64);

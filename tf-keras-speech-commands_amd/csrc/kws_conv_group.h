@@ -253,4 +253,75 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_dgrad_kernel(GroupD
     group_stats<kFuC3, kGrWaves / 4>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride);
 }
 
+// conv3's DATA gradient (3x3, stride 2): da2(y, x) = sum over the taps with y + 1 - kh and x + 1 - kw even and inside the 4 x 3 map of
+// dz3((y + 1 - kh) / 2, (x + 1 - kw) / 2) W[kh][kw]^T -- one to four taps per input pixel, none multiplied that is not needed.  dz3
+// (fp32, (B, 4, 3, 64)) is split once into bf16 planes while it is staged (the layout of conv4's forward A operand); 35 output positions
+// over eight position groups x two 16-channel column tiles; reduction over the 64 output channels of conv3 (two k-steps per tap).
+struct GroupDgrad3Args { const float *dz3; const __bf16 *fw[3]; float *da2; int B; };
+
+__global__ __launch_bounds__(kGrThreads, 1) void conv3_group_dgrad_kernel(GroupDgrad3Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) float gr_lds[];
+    __bf16 *D3 = reinterpret_cast<__bf16 *>(gr_lds);                            // three planes of kFuA3P, [position][clip][8 units of 8], swizzled
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lq = lane >> 4;
+    const int b0 = blockIdx.x * kFuClips;
+    const int sw = (li >> 1) & 7;
+    constexpr int NPOS = kFuH2 * kFuW2, NG = kGrWaves / 2, NP = (NPOS + NG - 1) / NG;     // 35 positions, 8 groups of 5
+    const int ct = wave & 1, grp = wave >> 1;
+    bf16x8 bw[3][3];
+    fu_load_b(g.fw, ct, lane, bw[0]);
+    fu_load_b(g.fw, 2 + ct, lane, bw[1]);
+    {
+        constexpr int PER = kFuH3 * kFuW3 * kFuC3 / 4;                          // float4 per clip: 192
+        for (int i = tid; i < kFuClips * PER; i += kGrThreads) {
+            const int c = i / PER, r = i - c * PER, pos = r >> 4, u4 = r & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b0 + c < g.B) v = *reinterpret_cast<const f32x4 *>(g.dz3 + ((long)(b0 + c) * PER + r) * 4);
+            bf16x4 h, m, l;
+            split_bf16(v, h, m, l);
+            const int e0 = ((pos * kFuClips + c) * 8 + ((u4 >> 1) ^ ((c >> 1) & 7))) * 8 + (u4 & 1) * 4;
+            *reinterpret_cast<bf16x4 *>(D3 + e0) = h;
+            *reinterpret_cast<bf16x4 *>(D3 + kFuA3P + e0) = m;
+            *reinterpret_cast<bf16x4 *>(D3 + 2 * kFuA3P + e0) = l;
+        }
+    }
+    __syncthreads();
+    f32x4 acc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ks3 = 0; ks3 < 18; ks3 += 3) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int ks = ks3 + d;
+            if (ks + 2 < 18) fu_load_b(g.fw, (long)(ks + 2) * 2 + ct, lane, bw[(d + 2) % 3]);
+            const int tap = ks >> 1, chunk = ks & 1, kh = tap / 3, kw = tap - kh * 3;
+            const int uo = ((4 * chunk + lq) ^ sw) * 8;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int pos = NP * grp + q, y = pos / kFuW2, x = pos - y * kFuW2;
+                const int sy = y + 1 - kh, sx = x + 1 - kw;
+                if (pos < NPOS && sy >= 0 && sx >= 0 && !((sy | sx) & 1) && (sy >> 1) < kFuH3 && (sx >> 1) < kFuW3) {
+                    const __bf16 *row = D3 + (((sy >> 1) * kFuW3 + (sx >> 1)) * kFuClips + li) * kFuC3 + uo;
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8 *>(row + p * kFuA3P);
+                    acc[q] = mfma_bf16x6(a, bw[d], acc[q]);
+                }
+            }
+        }
+    }
+    const int ch = 16 * ct + li;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pos = NP * grp + q;
+        if (pos < NPOS)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int clip = 4 * lq + r;
+                if (b0 + clip < g.B) g.da2[((long)(b0 + clip) * NPOS + pos) * kFuC2 + ch] = acc[q][r];
+            }
+    }
+}
+
 }  // namespace kws

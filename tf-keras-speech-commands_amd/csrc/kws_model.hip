@@ -350,7 +350,7 @@ static SplitDescs split_descs(const kws_model *m, const float *params, CnnWs &w,
     SplitDescs all{};
     const float *src[3] = {params + m->o_k[2], params + m->o_k[3], params + m->o_dk};
     const int taps[3] = {9, 9, m->d.H4 * m->d.W4}, ci[3] = {32, 64, 128}, co[3] = {64, 128, 128};
-    const int frag[3] = {group_fwd ? 1 : 0, group_fwd ? 2 : 0, 0}, ofrag[3] = {0, group_fwd ? 1 : 0, 0};
+    const int frag[3] = {group_fwd ? 1 : 0, group_fwd ? 2 : 0, 0}, ofrag[3] = {group_fwd ? 1 : 0, group_fwd ? 1 : 0, 0};
     for (int t = 0; t < 3; ++t)
         all.d[t] = SplitDesc{src[t], {w.wsp[t][0], w.wsp[t][1], w.wsp[t][2]}, {w.wsp[t][3], w.wsp[t][4], w.wsp[t][5]}, taps[t], ci[t], co[t], frag[t],
                              ofrag[t]};
@@ -372,6 +372,15 @@ static int launch_group_conv3(const kws_model *m, int B, CnnWs &w, hipStream_t s
     for (int p = 0; p < 3; ++p) a.f3[p] = w.wsp[0][3 + p];
     KWS_LAUNCH("conv_group_fwd<32,64>", conv3_group_fwd_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(4 * kFuA2), s, a);
     return (int)blocks_for(B, kFuClips);
+}
+static int launch_group_dgrad3(const kws_model *m, int B, CnnWs &w, hipStream_t s)
+{
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv3_group_dgrad_kernel), 6 * kFuA3P)) return rc;
+    GroupDgrad3Args a{};
+    a.dz3 = w.gz[2]; a.da2 = w.da[1]; a.B = B;
+    for (int p = 0; p < 3; ++p) a.fw[p] = w.wsp[0][p];
+    KWS_LAUNCH("conv_group_dgrad<64,32>", conv3_group_dgrad_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(6 * kFuA3P), s, a);
+    return KWS_OK;
 }
 static int launch_group_dgrad4(const kws_model *m, int B, CnnWs &w, hipStream_t s)
 {
@@ -831,7 +840,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
             if (mprec == 1) KWS_TRY(launch_wgrad_bf16<32, 64, 3>(in, w.gz[2], dk, g, s2, nullptr, det));
             else KWS_TRY(launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2, det));
-            KWS_TRY(launch_dgrad<64, 32, 2>(w.gz[2], kern, w.da[1], g, s));
+            if (mprec == 1 && group_fwd_ok(m) && (long)blocks_for(B, kFuClips) <= kStatStride) KWS_TRY(launch_group_dgrad3(m, B, w, s));
+            else KWS_TRY(launch_dgrad<64, 32, 2>(w.gz[2], kern, w.da[1], g, s));
         } else {
             // conv2 (16 -> 32, 3x3, stride 1): clip-resident kernels, the clip's tiles are staged in LDS once
             const int H1 = Hs[1], W1 = Ws[1];

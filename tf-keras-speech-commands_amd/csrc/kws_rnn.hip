@@ -50,13 +50,13 @@ int launch_fwd(const kws_model *m, const float *feat, int B, const float *params
             if (smem > 64 * 1024)
                 KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_fwd_kernel<KX, true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            KWS_LAUNCH("lstm_fwd_kernel", (lstm_fwd_kernel<KX, true>), dim3(blocks_for(B, 16)), dim3(192), smem, s, feat, params + m->o_rk,
+            KWS_LAUNCH("lstm_fwd_kernel", (lstm_fwd_kernel<KX, true>), dim3(blocks_for(B, 16)), dim3(kLstmFwdThreads), smem, s, feat, params + m->o_rk,
                        params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi);
         } else {
             if (smem > 64 * 1024)
                 KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_fwd_kernel<KX, false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            KWS_LAUNCH("lstm_fwd_kernel", (lstm_fwd_kernel<KX, false>), dim3(blocks_for(B, 16)), dim3(192), smem, s, feat, params + m->o_rk,
+            KWS_LAUNCH("lstm_fwd_kernel", (lstm_fwd_kernel<KX, false>), dim3(blocks_for(B, 16)), dim3(kLstmFwdThreads), smem, s, feat, params + m->o_rk,
                        params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi);
         }
         KWS_LAUNCH_CHECK("lstm_fwd_kernel");
@@ -91,7 +91,7 @@ int launch_bwd(const kws_model *m, const float *feat, int B, const float *params
         if (smem > 64 * 1024)
             KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_bwd_kernel<KX>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        KWS_LAUNCH("lstm_bwd_kernel", lstm_bwd_kernel<KX>, dim3(blocks_for(B, 16)), dim3(192), smem, s, feat, params + m->o_ru, w.saved,
+        KWS_LAUNCH("lstm_bwd_kernel", lstm_bwd_kernel<KX>, dim3(blocks_for(B, 16)), dim3(kLstmBwdThreads), smem, s, feat, params + m->o_ru, w.saved,
                    w.dh_last, grads + m->o_rk, grads + m->o_ru, grads + m->o_rb, B, T, F, rate, slo, shi);
         KWS_LAUNCH_CHECK("lstm_bwd_kernel");
         return KWS_OK;

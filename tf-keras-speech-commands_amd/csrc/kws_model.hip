@@ -19,6 +19,7 @@
 #include "kws_lite_f16.h"
 #include "kws_infer_fused.h"
 #include "kws_conv_group.h"
+#include "kws_dense_head.h"
 
 using namespace kws;
 
@@ -345,12 +346,19 @@ static bool group_fwd_ok(const kws_model *m)
     const CnnDims &d = m->d;
     return m->kind == KWS_SIMPLE_CNN && d.H2 == kFuH2 && d.W2 == kFuW2 && d.H3 == kFuH3 && d.W3 == kFuW3;
 }
-static SplitDescs split_descs(const kws_model *m, const float *params, CnnWs &w, bool group_fwd = false)
+// non-deterministic training in split precision: Dense forward, head forward / backward and the Dense data gradient are one kernel
+// (kws_dense_head.h), whose Dense weights are fragment-major in both orders
+static bool dense_head_fused_ok(const kws_model *m, int mprec)
+{
+    return m->kind == KWS_SIMPLE_CNN && mprec == 1 && !m->deterministic && head_bwd_fuses(m) && m->head_K == kDhK && m->d.flat % 64 == 0 &&
+           m->d.flat <= 1024;
+}
+static SplitDescs split_descs(const kws_model *m, const float *params, CnnWs &w, bool group_fwd = false, bool dense_fused = false)
 {
     SplitDescs all{};
     const float *src[3] = {params + m->o_k[2], params + m->o_k[3], params + m->o_dk};
     const int taps[3] = {9, 9, m->d.H4 * m->d.W4}, ci[3] = {32, 64, 128}, co[3] = {64, 128, 128};
-    const int frag[3] = {group_fwd ? 1 : 0, group_fwd ? 2 : 0, 0}, ofrag[3] = {group_fwd ? 1 : 0, group_fwd ? 1 : 0, 0};
+    const int frag[3] = {group_fwd ? 1 : 0, group_fwd ? 2 : 0, dense_fused ? 1 : 0}, ofrag[3] = {group_fwd ? 1 : 0, group_fwd ? 1 : 0, dense_fused ? 1 : 0};
     for (int t = 0; t < 3; ++t)
         all.d[t] = SplitDesc{src[t], {w.wsp[t][0], w.wsp[t][1], w.wsp[t][2]}, {w.wsp[t][3], w.wsp[t][4], w.wsp[t][5]}, taps[t], ci[t], co[t], frag[t],
                              ofrag[t]};
@@ -358,9 +366,9 @@ static SplitDescs split_descs(const kws_model *m, const float *params, CnnWs &w,
     return all;
 }
 
-static int split_weights(const kws_model *m, const float *params, CnnWs &w, hipStream_t s, bool group_fwd = false)
+static int split_weights(const kws_model *m, const float *params, CnnWs &w, hipStream_t s, bool group_fwd = false, bool dense_fused = false)
 {
-    const SplitDescs all = split_descs(m, params, w, group_fwd);
+    const SplitDescs all = split_descs(m, params, w, group_fwd, dense_fused);
     KWS_LAUNCH("weight_split_kernel", weight_split_kernel, dim3(64, 3), dim3(256), 0, s, all);
     return KWS_OK;
 }
@@ -482,6 +490,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool fused_tail = !training && head_done && fused_tail_ok(m, bf16);
     // training in split precision at the default geometry: conv3 / conv4 forward as clip-group kernels (needs at most kStatStride blocks)
     const bool group_fwd = training && bf16 && group_fwd_ok(m) && (long)blocks_for(B, kFuClips) <= kStatStride;
+    // training: the Dense layer's forward product runs inside the fused Dense + head kernel of the backward pass (kws_dense_head.h)
+    const bool dense_fused = training && dense_head_fused_ok(m, matrix_prec(m));
     ModelRes *R = nullptr;       // only the split-on-the-side-stream branch below needs the model's stream / events
     // training in split precision at a geometry the MFMA layer-1 kernels cover: the weight split and the gradient clear ride
     // in the grid of the layer-1 activation kernel -- no side-stream branch, no events
@@ -500,7 +510,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             KWS_HIP_CHECK(hipMemsetAsync(zero_grads, 0, sizeof(float) * (size_t)m->P, s2));
             if (zeroed) *zeroed = true;
         }
-        if (int rc = split_weights(m, params, w, s2, group_fwd)) return rc;
+        if (int rc = split_weights(m, params, w, s2, group_fwd, dense_fused)) return rc;
         KWS_HIP_CHECK(hipEventRecord(R->ev[11], s2));
     } else if (bf16) {
         // inference stays on ONE stream: callers capture it into hipGraphs, and a fork to the library's side stream inside
@@ -534,7 +544,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             }
             L1PrepArgs pa{};
             if (prep_in_stats) {
-                pa.all = split_descs(m, params, w, group_fwd); pa.zero_buf = zero_grads; pa.zero_n = (long)m->P;
+                pa.all = split_descs(m, params, w, group_fwd, dense_fused); pa.zero_buf = zero_grads; pa.zero_n = (long)m->P;
                 pa.nsplit = kPrepSplitBlocks; pa.nzero = kPrepZeroBlocks;
                 KWS_LAUNCH("l1m_act_pool_kernel", l1m_act_pool_moments_kernel<true>, dim3(nbm + kPrepBlocks), dim3(256), smemm, s, feat, kern1, q,
                            params + m->o_g[0], params + m->o_b[0], state + m->o_mm[0], state + m->o_mv[0], k1, w.a[0], B, d.H0, d.W0, cpw, nbm, pa);
@@ -660,7 +670,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     ConvGeom g;
     g.B = B; g.H = d.H4; g.W = d.W4; g.Ho = 1; g.Wo = 1; g.stride = 1; g.pt = 0; g.pl = 0; g.KH = d.H4; g.KW = d.W4;
     if (hook) KWS_TRY(hook->fire(6, s, bound6));
-    if (bf16) KWS_TRY_NB(launch_bf16<128, 128, MODE_FWD, EPI_BIAS_RELU6>("conv_bf16_fwd", w.a[3], w.wsp[2], params + m->o_db, w.d1, g, s));
+    if (dense_fused) ;                              // d1 is formed by dense_head_fused_kernel (cnn_backward)
+    else if (bf16) KWS_TRY_NB(launch_bf16<128, 128, MODE_FWD, EPI_BIAS_RELU6>("conv_bf16_fwd", w.a[3], w.wsp[2], params + m->o_db, w.d1, g, s));
     else KWS_TRY(launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s));
     if (hook) KWS_TRY(hook->fire(7, s));
     KWS_LAUNCH_CHECK("simple_cnn forward");
@@ -694,7 +705,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     // kernel's own completion signal be the event (kws_common.h: ArmedEvent) instead of a marker packet on the main chain
     constexpr bool no_arm = false;
     hipEvent_t fork0_ev = nullptr;
-    bool fork0_bound = false;
+    bool fork0_bound = false, dense_fused = false;
     auto arm = [&](int ev) { if (!no_arm) arm_stop_event(R->ev[ev], s); };
     auto fork = [&](int ev) -> int {
         if (!stop_event_bound(R->ev[ev])) KWS_HIP_CHECK(hipEventRecord(R->ev[ev], s));
@@ -710,7 +721,19 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         // (deterministic mode launches two kernels here and keeps the recorded events)
         fork0_ev = (hook && hook->wants(2) && hook->ev) ? hook->ev : R->ev[0];
         if (!det && !no_arm) arm_stop_event(fork0_ev, s);
-        if (fused_head) {
+        if (fused_head && dense_head_fused_ok(m, mprec)) {
+            const kws_train_args *a = fused_head;
+            DenseHeadArgs da{};
+            da.a4 = w.a[3]; da.db = params + m->o_db; da.w2 = params + m->o_hk;
+            for (int p = 0; p < 3; ++p) { da.fd[p] = w.wsp[2][3 + p]; da.fo[p] = w.wsp[2][p]; }
+            da.d1 = w.d1; da.dd1 = w.dd1; da.da4 = w.da4; da.dw2 = grads + m->o_hk; da.db2 = grads + m->o_hb; da.ddb = grads + m->o_db;
+            da.B = B; da.C = m->C; da.flat = d.flat;
+            da.fw = HeadFwdArgs{params + m->o_hb, a->labels, a->class_weights, a->probs, w.loss_i, w.correct_i, a->grad_scale / (float)B, a->ignore_index};
+            const size_t smem = sizeof(float) * (size_t)(16 * (d.flat + 8) + 2 * 16 * kDhKS + 16 * kDhCS + kDhK * kDhCS);
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(dense_head_fused_kernel), (int)smem)) return rc;
+            KWS_LAUNCH("dense_head_fused_kernel", dense_head_fused_kernel, dim3(blocks_for(B, 16)), dim3(256), smem, s, da);
+            dense_fused = true;
+        } else if (fused_head) {
             const kws_train_args *a = fused_head;
             const HeadFwdArgs hf{params + m->o_hb, a->labels, a->class_weights, a->probs, w.loss_i, w.correct_i, a->grad_scale / (float)B, a->ignore_index};
             KWS_TRY(run_head_bwd(m, B, params, w.d1, nullptr, w.dd1, grads, true, s, grads + m->o_db, nullptr, nullptr, nullptr, false, &hf));
@@ -746,7 +769,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             KWS_LAUNCH("channel_stats_kernel.dense", channel_stats_kernel, dim3(nblk), dim3(256), 0, s, w.dd1, (long)B, 128, rows, w.partial);
             KWS_LAUNCH("colsum_finalize_kernel", colsum_finalize_kernel, dim3(128), dim3(256), 0, s, w.partial, nblk, 128, grads + m->o_db);
         }
-        if (mprec == 1) KWS_TRY_NB(launch_bf16<128, 128, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.dd1, w.wsp[2], nullptr, w.da4, g, s));
+        if (dense_fused) ;                          // da4 came out of dense_head_fused_kernel
+        else if (mprec == 1) KWS_TRY_NB(launch_bf16<128, 128, MODE_DGRAD, EPI_NONE>("conv_bf16_dgrad", w.dd1, w.wsp[2], nullptr, w.da4, g, s));
         else KWS_TRY(launch_dgrad<128, 128, 1>(w.dd1, params + m->o_dk, w.da4, g, s));
         if (hook) KWS_TRY(hook->fire(3, s));
     }

@@ -528,6 +528,8 @@ def main():
     ap.add_argument("--extra-only", action="store_true", help="(internal) run the SURVEY 8(d) side workloads and print their JSON")
     ap.add_argument("--force-comm", action="store_true",
                     help="run the RCCL exchange (kws_allreduce_grads) even in a one-rank world: rehearsal of the N > 1 code path on one GPU")
+    ap.add_argument("--overlap-point", type=int, default=-1,
+                    help="(tuning) where in the step the next batch's featurizer starts: kws_model_set_overlap_point, -1 = the library's choice")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: bring up the ranks (gloo), check the process group and the shard plan of the global batch, print a JSON line, exit")
     args = ap.parse_args()
@@ -576,6 +578,8 @@ def main():
     spec = ModelSpec("simple_cnn", N_CLASSES, pr.n_features, pr.feature_size)
     dm = DeviceModel(spec)
     dm.set_weights(init_weights(spec, seed=0))   # glorot-uniform kernels, default_rng(0)
+    if args.overlap_point >= 0:
+        dm.set_overlap_point(args.overlap_point)
     wav_np, lab_np = synthetic_batch(B, rank, N_CLASSES)
     wav = torch.from_numpy(wav_np).cuda()
     labels = torch.from_numpy(lab_np).cuda()

@@ -39,7 +39,11 @@ SHORT = [("featurize_fft1024_v3_kernel<float", "featurize_fft1024_f32"), ("featu
          ("conv_bf16_kernel<128, 64, 1", "conv_bf16_dgrad<128,64>"), ("conv_bf16_kernel<128, 128, 1", "conv_bf16_dgrad<128,128>"),
          ("conv_dgrad_direct_kernel<64, 32", "conv_dgrad<64,32>"), ("conv_wgrad_direct_kernel<128, 128", "conv_wgrad<128,128>"),
          ("head_bwd_mfma_kernel<true", "head_fwd_bwd_kernel"), ("l1f_bwd_onepass_kernel", "l1m_bwd_onepass_kernel"),
-         ("l1m_act_pool_moments_kernel", "l1m_act_pool_kernel"), ("l1_moments_kernel", "l1_moments_kernel"), ("infer_tail_kernel", "infer_tail_kernel")]
+         ("l1m_act_pool_moments_kernel", "l1m_act_pool_kernel"), ("l1_moments_kernel", "l1_moments_kernel"), ("infer_tail_kernel", "infer_tail_kernel"),
+         ("conv3_group_fwd_kernel", "conv_group_fwd<32,64>"), ("conv4_group_fwd_kernel", "conv_group_fwd<64,128>"),
+         ("conv4_group_dgrad_kernel", "conv_group_dgrad<128,64>"), ("conv3_group_dgrad_kernel", "conv_group_dgrad<64,32>"),
+         ("dense_head_fused_kernel", "dense_head_fused_kernel")]
+ITERS = {"step": 5}          # iterations the workload command runs (workload.py: default 3; step = 3 timed + 2 warm-up bench steps)
 
 
 def derived(c, launches_note=None):
@@ -121,11 +125,16 @@ def main():
                 continue
             e = {n: v for n, v in c.items() if not n.startswith("_")}
             e["derived"] = derived(c)
+            launches = max([v for n, v in c.items() if n.startswith("_launches_")] or [0])
+            e["launches_per_iteration"] = round(launches / float(ITERS.get(name, 3)), 3)
             if k in avg:
                 e["rocprofv3_avg_ms"] = round(avg[k], 5)
             short = [s for pat, s in SHORT if pat in k]
             kernels[short[0] if short else k] = dict(e, symbol=k)
-        out[name] = {"kernels": kernels, "_avg_ms": avg, "command": "python3 tools/workload.py " + name, "source_sha1": bid}
+        tot = sum(v["derived"].get("hbm_bytes", 0) * v["launches_per_iteration"] for v in kernels.values())
+        out[name] = {"kernels": kernels, "_avg_ms": avg, "command": "python3 tools/workload.py " + name, "source_sha1": bid,
+                     "hbm_bytes_per_iteration": int(tot),
+                     "hbm_bytes_per_iteration_note": "sum over the workload's kernels of (HBM bytes per launch by counters) x (launches per iteration)"}
         print(name, {k: (v.get("rocprofv3_avg_ms"), v["derived"].get("bound_by")) for k, v in kernels.items()}, flush=True)
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -63,6 +63,13 @@ def get_lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libkws_hip.so is missing at %s: build it with `python -m kws_amd.build` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 and the host side of this package uses torch for device memory and
+    # streams, so torch is loaded FIRST and libkws_hip.so binds to the runtime it brought.  Loaded the other way round (this library, then
+    # torch) the process holds two runtimes and the second one sees no device (__graft_entry__: build() followed by smoke() in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass                    # a torch-free host (tests of the C ABI alone): the system runtime the library links against
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, fp = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
     L.kws_version.restype = ctypes.c_char_p

@@ -33,7 +33,13 @@ __device__ __forceinline__ void group_stats(float s, float ss, int ch, int grp, 
     }
 }
 
-struct GroupConv3Args { const float *a2; const __bf16 *f3[3]; float *z3; double *partial; int stride, B; };
+// z2 != nullptr: the kernel is ALSO layer 2's activation pass -- a2 = maxpool(relu6(BN2(z2))) is formed from z2 (B, 15, 10, 32) while the tile is
+// staged and written to `a2w` for the backward pass together with the routed element of every window (zmax2: its pre-BatchNorm value,
+// arg2: its index 0..3, first maximum of relu6(y): the contract of bn_act_pool_kernel<true>, kws_layers.h), so that kernel's launch and
+// the a2 round trip (18 MB each way) are gone.
+struct GroupConv3Args { const float *a2; const __bf16 *f3[3]; float *z3; double *partial; int stride, B;
+                        const float *z2, *sc2, *sh2; float *a2w, *zmax2; unsigned char *arg2; };
+constexpr int kGrH1 = 2 * kFuH2 + 1, kGrW1 = 2 * kFuW2;                         // conv2's map: 15 x 10 (the last row falls out of the 'valid' pooling)
 
 __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_fwd_kernel(GroupConv3Args g)
 {
@@ -52,7 +58,35 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_fwd_kernel(GroupCon
         for (int i = tid; i < kFuClips * PER; i += kGrThreads) {
             const int c = i / PER, r = i - c * PER, px = r >> 3, u = r & 7;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b0 + c < g.B) v = *reinterpret_cast<const f32x4 *>(g.a2 + ((long)(b0 + c) * PER + r) * 4);
+            if (b0 + c < g.B) {
+                if (g.z2) {
+                    const int ph = px / kFuW2, pw = px - ph * kFuW2;
+                    const float *zp = g.z2 + ((((long)(b0 + c) * kGrH1 + 2 * ph) * kGrW1 + 2 * pw) * kFuC2 + 4 * u);
+                    const f32x4 z0 = *reinterpret_cast<const f32x4 *>(zp), z1 = *reinterpret_cast<const f32x4 *>(zp + kFuC2);
+                    const f32x4 z2v = *reinterpret_cast<const f32x4 *>(zp + kGrW1 * kFuC2), z3v = *reinterpret_cast<const f32x4 *>(zp + kGrW1 * kFuC2 + kFuC2);
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(g.sc2 + 4 * u), sh = *reinterpret_cast<const f32x4 *>(g.sh2 + 4 * u);
+                    f32x4 zm;
+                    unsigned am = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y0 = fmaf(z0[e], sc[e], sh[e]), y1 = fmaf(z1[e], sc[e], sh[e]), y2 = fmaf(z2v[e], sc[e], sh[e]), y3 = fmaf(z3v[e], sc[e], sh[e]);
+                        v[e] = relu6f(fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
+                        unsigned arg = 0u;                   // first maximum of relu6(y): the element the backward pass routes the gradient to
+                        float best = relu6f(y0), zz = z0[e];
+                        const float v1 = relu6f(y1), v2 = relu6f(y2), v3 = relu6f(y3);
+                        if (v1 > best) { best = v1; arg = 1u; zz = z1[e]; }
+                        if (v2 > best) { best = v2; arg = 2u; zz = z2v[e]; }
+                        if (v3 > best) { arg = 3u; zz = z3v[e]; }
+                        zm[e] = zz;
+                        am |= arg << (8 * e);
+                    }
+                    const long o = ((long)(b0 + c) * PER + r) * 4;
+                    *reinterpret_cast<f32x4 *>(g.a2w + o) = v;
+                    *reinterpret_cast<f32x4 *>(g.zmax2 + o) = zm;
+                    *reinterpret_cast<unsigned *>(g.arg2 + o) = am;
+                } else
+                    v = *reinterpret_cast<const f32x4 *>(g.a2 + ((long)(b0 + c) * PER + r) * 4);
+            }
             *reinterpret_cast<f32x4 *>(A2 + ((px * kFuClips + c) * 8 + (u ^ ((c >> 1) & 7))) * 4) = v;
         }
     }

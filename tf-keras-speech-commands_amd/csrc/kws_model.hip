@@ -372,11 +372,15 @@ static int split_weights(const kws_model *m, const float *params, CnnWs &w, hipS
     KWS_LAUNCH("weight_split_kernel", weight_split_kernel, dim3(64, 3), dim3(256), 0, s, all);
     return KWS_OK;
 }
-static int launch_group_conv3(const kws_model *m, int B, CnnWs &w, hipStream_t s)
+static int launch_group_conv3(const kws_model *m, int B, CnnWs &w, hipStream_t s, bool fuse_pool2)
 {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv3_group_fwd_kernel), 4 * kFuA2)) return rc;
     GroupConv3Args a{};
     a.a2 = w.a[1]; a.z3 = w.z[2]; a.partial = w.partial; a.stride = kStatStride; a.B = B;
+    if (fuse_pool2) {            // layer 2's BatchNorm -> ReLU6 -> max-pool happens while the tile is staged (bn_act_pool_kernel<true>'s contract)
+        const BnCoef k2 = coef_of(w.coef[1], 32);
+        a.z2 = w.z[1]; a.sc2 = k2.scale; a.sh2 = k2.shift; a.a2w = w.a[1]; a.zmax2 = w.zmax2; a.arg2 = w.arg2;
+    }
     for (int p = 0; p < 3; ++p) a.f3[p] = w.wsp[0][3 + p];
     KWS_LAUNCH("conv_group_fwd<32,64>", conv3_group_fwd_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(4 * kFuA2), s, a);
     return (int)blocks_for(B, kFuClips);
@@ -566,6 +570,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     bool bound6 = false;
     const bool a3_on_load = cnn_a3_on_load(m, bf16, training);
     const bool routed_bwd2 = cnn_compact_g2(m, bf16);
+    const bool fuse_pool2 = group_fwd && routed_bwd2 && d.H1 == kGrH1 && d.W1 == kGrW1;
     for (int l = 1; l < 4; ++l) {
         const float *in = w.a[l - 1];
         const float *kern = params + m->o_k[l];
@@ -612,7 +617,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             if (bf16 && training && !prep_in_stats) KWS_HIP_CHECK(hipStreamWaitEvent(s, R->ev[11], 0));     // the weight planes are ready
             // the split-precision kernels write the BatchNorm partial sums from their epilogue when training
             if (group_fwd) {
-                fused_stat_blocks = launch_group_conv3(m, B, w, s);
+                fused_stat_blocks = launch_group_conv3(m, B, w, s, fuse_pool2);
                 if (fused_stat_blocks < 0) return fused_stat_blocks;
             } else if (bf16) {
                 fused_stat_blocks = launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s,
@@ -650,7 +655,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         // instead of a marker packet of its own (kws_common.h: ArmedEvent)
         const bool arm6 = l == 3 && hook && hook->wants(6) && hook->ev;
         if (arm6) arm_stop_event(hook->ev, s);
-        if (pool[l]) {
+        if (l == 1 && fuse_pool2) ;                    // conv3's group kernel forms a2 (and zmax2 / arg2) from z2 while it stages its tile
+        else if (pool[l]) {
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
             // training: the routed element of every window for the backward reduction (layer 2: compact g; layer 4: full-size g)
             float *zm = nullptr;

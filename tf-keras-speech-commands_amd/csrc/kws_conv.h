@@ -1315,7 +1315,26 @@ struct BnBwdArgs {
     // gw == nullptr: g is read full-size from the dz buffer
     const float *gw = nullptr;
     const unsigned char *arg = nullptr;
+    // acc != nullptr (split-precision clip kernels): the sums of g and g xhat sit in an accumulator set (kws_device.h: acc_add) and the
+    // kernel derives k2 = sum g / M, k3 = sum g xhat / M itself; the kernel that is given dgamma also writes dgamma, dbeta, k2, k3 and clears
+    // acc_clear_set (block 0) -- what bn_bwd_finalize_kernel did
+    const double *acc = nullptr;
+    double *acc_clear_set = nullptr;
+    long M = 1;
+    float *dgamma = nullptr, *dbeta = nullptr, *k2w = nullptr, *k3w = nullptr;
 };
+// k2 / k3 of this thread's channels 4 c4 .. 4 c4 + 3 (of C) from the accumulator set; `writer`: this thread also leaves the finalize outputs
+__device__ __forceinline__ void bn_bwd_k_from_acc(const BnBwdArgs &bn, int C, int c4, bool writer, float *k2, float *k3)
+{
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * c4 + e;
+        const double s = acc_sum(bn.acc, 2 * C, c), sx = acc_sum(bn.acc, 2 * C, C + c);
+        k2[e] = (float)(s / (double)bn.M);
+        k3[e] = (float)(sx / (double)bn.M);
+        if (writer) { bn.dbeta[c] = (float)s; bn.dgamma[c] = (float)sx; bn.k2w[c] = k2[e]; bn.k3w[c] = k3[e]; }
+    }
+}
 template <int CR, bool BN>
 __global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(float *__restrict__ dz, const float *__restrict__ wgt,
                                                                float *__restrict__ dx, int B, int H, int W, BnBwdArgs bn)
@@ -1458,7 +1477,13 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__r
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = 4 * (threadIdx.x % F4) + e;
-            inv[e] = bn.inv[c]; gi[e] = bn.gamma[c] * inv[e]; mean[e] = bn.mean[c]; k2[e] = bn.k2[c]; k3[e] = bn.k3[c];
+            inv[e] = bn.inv[c]; gi[e] = bn.gamma[c] * inv[e]; mean[e] = bn.mean[c];
+            if (!bn.acc) { k2[e] = bn.k2[c]; k3[e] = bn.k3[c]; }
+        }
+        if (bn.acc) {
+            const bool writer = bn.dgamma && blockIdx.x == 0 && (int)threadIdx.x < F4;
+            bn_bwd_k_from_acc(bn, 4 * F4, threadIdx.x % F4, writer, k2, k3);
+            if (bn.acc_clear_set && blockIdx.x == 0) acc_clear(bn.acc_clear_set, threadIdx.x, 256);
         }
     }
     auto bn_apply = [&](f32x4 g, f32x4 zv) {
@@ -1615,8 +1640,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_clip_bf16_kernel(const floa
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int c = 4 * (threadIdx.x % F4) + e;
-            inv[e] = bn.inv[c]; gi[e] = bn.gamma[c] * inv[e]; mean[e] = bn.mean[c]; k2[e] = bn.k2[c]; k3[e] = bn.k3[c];
+            inv[e] = bn.inv[c]; gi[e] = bn.gamma[c] * inv[e]; mean[e] = bn.mean[c];
+            if (!bn.acc) { k2[e] = bn.k2[c]; k3[e] = bn.k3[c]; }
         }
+        if (bn.acc) bn_bwd_k_from_acc(bn, COUT, threadIdx.x % F4, false, k2, k3);
 #pragma unroll
         for (int j = 0; j < PD; ++j) {
             const int i = threadIdx.x + 256 * j, pix = i / F4, c4 = i % F4, y = pix / W, xx = pix - y * W;

@@ -15,9 +15,11 @@ namespace kws {
 
 constexpr int kGrThreads = 1024, kGrWaves = kGrThreads / 64;
 
-// partial[(which * C + ch) * stride + blockIdx.x] = this block's sum / sum of squares of channel ch; `red` = 2 * G * C doubles of LDS
+// partial[(which * C + ch) * stride + blockIdx.x] = this block's sum / sum of squares of channel ch; `red` = 2 * G * C doubles of LDS.
+// acc != nullptr: the sums are added to that accumulator set instead (kws_device.h: acc_add) and no finalize kernel follows
 template <int C, int G>
-__device__ __forceinline__ void group_stats(float s, float ss, int ch, int grp, int lq, double *red, double *__restrict__ partial, int stride)
+__device__ __forceinline__ void group_stats(float s, float ss, int ch, int grp, int lq, double *red, double *__restrict__ partial, int stride,
+                                            double *__restrict__ acc = nullptr)
 {
     double a = (double)s, q = (double)ss;
     a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
@@ -29,7 +31,8 @@ __device__ __forceinline__ void group_stats(float s, float ss, int ch, int grp, 
         double t = 0.0;
 #pragma unroll
         for (int g2 = 0; g2 < G; ++g2) t += red[(g2 * 2 + which) * C + n];          // fixed order: deterministic
-        partial[((long)which * C + n) * stride + blockIdx.x] = t;
+        if (acc) acc_add(acc, 2 * C, i, t);
+        else partial[((long)which * C + n) * stride + blockIdx.x] = t;
     }
 }
 
@@ -291,7 +294,10 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_dgrad_kernel(GroupD
 // dz3((y + 1 - kh) / 2, (x + 1 - kw) / 2) W[kh][kw]^T -- one to four taps per input pixel, none multiplied that is not needed.  dz3
 // (fp32, (B, 4, 3, 64)) is split once into bf16 planes while it is staged (the layout of conv4's forward A operand); 35 output positions
 // over eight position groups x two 16-channel column tiles; reduction over the 64 output channels of conv3 (two k-steps per tap).
-struct GroupDgrad3Args { const float *dz3; const __bf16 *fw[3]; float *da2; int B; };
+// acc != nullptr: the epilogue is ALSO BatchNorm-2's backward reduction over the routed elements (the contract of
+// bn_bwd_reduce_routed_kernel, kws_layers.h): da2 is gated by ReLU6(BN2(zmax2)) before it is stored, and the block's sums of g and
+// g xhat go to the accumulator set -- that kernel's launch (37 us in the step) and the second pass over da2 / zmax2 are gone.
+struct GroupDgrad3Args { const float *dz3; const __bf16 *fw[3]; float *da2; int B; const float *zmax2, *coef2; double *acc; };
 
 __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_dgrad_kernel(GroupDgrad3Args g)
 {
@@ -346,6 +352,29 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_dgrad_kernel(GroupD
         }
     }
     const int ch = 16 * ct + li;
+    if (g.acc) {
+        const float gsc = g.coef2[ch], gsh = g.coef2[kFuC2 + ch], gmean = g.coef2[2 * kFuC2 + ch], ginv = g.coef2[3 * kFuC2 + ch];
+        float s = 0.f, sx = 0.f;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int pos = NP * grp + q;
+            if (pos < NPOS)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int clip = 4 * lq + r;
+                    if (b0 + clip < g.B) {
+                        const long e = ((long)(b0 + clip) * NPOS + pos) * kFuC2 + ch;
+                        const float za = g.zmax2[e], ya = fmaf(za, gsc, gsh);
+                        const float v = (ya > 0.f && ya < 6.f) ? acc[q][r] : 0.f;
+                        g.da2[e] = v;
+                        s += v; sx = fmaf(v, (za - gmean) * ginv, sx);
+                    }
+                }
+        }
+        __syncthreads();
+        group_stats<kFuC2, NG>(s, sx, ch, grp, lq, reinterpret_cast<double *>(gr_lds), nullptr, 0, g.acc);
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int pos = NP * grp + q;

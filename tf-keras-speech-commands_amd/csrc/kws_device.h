@@ -103,4 +103,35 @@ struct HeadFwdArgs {
     int ignore_index;
 };
 
+// ---- BatchNorm sums without a finalize launch ------------------------------------------------------------------
+// The partial-sum form (kws_layers.h: partial[(which*C + c)*kStatStride + blk] + a finalize kernel) costs a launch between every producer and consumer of the main chain (6-9 us each of pure dependency
+// latency, seven per train step).  In the accumulator form the producer's blocks ADD their per-channel sums (double,
+// global_atomic_add_f64) into one small set, [kAccSlots][2][C], slot = blockIdx & 7 -- with one slot the ~1000 same-address atomics of a
+// persistent grid that ends in a burst serialise (+5..12 us, tools/atomic_calib.hip); with eight they cost < 1 us -- and every CONSUMER
+// block derives the coefficients itself in its prologue (2 C x 8 doubles from L2, same order and arithmetic in every block, so all
+// blocks and all consumer kernels see bit-identical coefficients).  One designated consumer block also writes what the finalize kernel
+// wrote (the coefficient arrays, moving statistics / dgamma, dbeta) and clears the set of the OTHER parity: sets alternate between
+// consecutive passes, so a set is cleared one pass before it is added to and nothing on the chain waits for a memset.  The sets live
+// in the model's own device memory (ModelRes), zero at creation.  The order of the atomics is not fixed: deterministic mode keeps the
+// partial-sum form.
+constexpr int kAccSlots = 8, kAccDoubles = kAccSlots * 2 * 128;
+__device__ __forceinline__ void acc_add(double *__restrict__ acc, int C2, int i, double v)
+{
+    atomicAdd(acc + (blockIdx.x & (kAccSlots - 1)) * C2 + i, v);
+}
+__device__ __forceinline__ double acc_sum(const double *__restrict__ acc, int C2, int i)
+{
+    double v[kAccSlots];
+#pragma unroll
+    for (int j = 0; j < kAccSlots; ++j) v[j] = acc[j * C2 + i];
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < kAccSlots; ++j) t += v[j];
+    return t;
+}
+__device__ __forceinline__ void acc_clear(double *__restrict__ acc, int tid, int nthreads)
+{
+    for (int i = tid; i < kAccDoubles; i += nthreads) acc[i] = 0.0;
+}
+
 }  // namespace kws

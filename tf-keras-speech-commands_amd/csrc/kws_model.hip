@@ -127,6 +127,16 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
 }
 
 BnCoef coef_of(float *base, int C) { return BnCoef{base, base + C, base + 2 * C, base + 3 * C, base + 4 * C, base + 5 * C}; }
+// accumulator set of (pass, layer, parity) -- kws_model_types.h: ModelRes::acc
+static double *acc_set(ModelRes *R, int pass, int layer, unsigned parity) { return R->acc + ((size_t)(pass * 4 + layer) * 2 + (parity & 1u)) * kAccDoubles; }
+static int acc_make_clean(ModelRes *R, hipStream_t s)
+{
+    if (R->acc_dirty) {
+        KWS_HIP_CHECK(hipMemsetAsync(R->acc, 0, sizeof(double) * 2 * 4 * 2 * kAccDoubles, s));
+        R->acc_dirty = false;
+    }
+    return KWS_OK;
+}
 
 // inference: scale / shift of all four BatchNorm layers in one launch
 static int infer_coefs(const kws_model *m, const float *params, const float *state, CnnWs &w, hipStream_t s)
@@ -385,11 +395,12 @@ static int launch_group_conv3(const kws_model *m, int B, CnnWs &w, hipStream_t s
     KWS_LAUNCH("conv_group_fwd<32,64>", conv3_group_fwd_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(4 * kFuA2), s, a);
     return (int)blocks_for(B, kFuClips);
 }
-static int launch_group_dgrad3(const kws_model *m, int B, CnnWs &w, hipStream_t s)
+static int launch_group_dgrad3(const kws_model *m, int B, CnnWs &w, hipStream_t s, double *acc2 = nullptr)
 {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv3_group_dgrad_kernel), 6 * kFuA3P)) return rc;
     GroupDgrad3Args a{};
     a.dz3 = w.gz[2]; a.da2 = w.da[1]; a.B = B;
+    a.zmax2 = w.zmax2; a.coef2 = coef_of(w.coef[1], 32).scale; a.acc = acc2;      // acc2: BatchNorm-2's backward reduction in the epilogue
     for (int p = 0; p < 3; ++p) a.fw[p] = w.wsp[0][p];
     KWS_LAUNCH("conv_group_dgrad<64,32>", conv3_group_dgrad_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(6 * kFuA3P), s, a);
     return KWS_OK;
@@ -782,6 +793,14 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     }
     int fused_bn3_blocks = 0;          // > 0: conv4's data gradient already did layer 3's BatchNorm-backward reduction
     const bool routed_bwd2 = cnn_compact_g2(m, mprec == 1);      // the forward pass left zmax2 / arg2 (same predicate)
+    // the clip-group form of conv4's / conv3's data gradients (the forward pass prepared the weights for it: cnn_forward's group_fwd)
+    const bool group_bwd = mprec == 1 && group_fwd_ok(m) && (long)blocks_for(B, kFuClips) <= kStatStride;
+    // finalize-free BatchNorm backward (kws_device.h: acc_add), non-deterministic mode: conv3's data gradient does layer 2's reduction in
+    // its epilogue and conv2's clip kernels derive k2 / k3 from the accumulator set
+    const bool acc_bn2 = group_bwd && !det && routed_bwd2 && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
+    const unsigned par = R->bwd_passes++;
+    KWS_TRY(acc_make_clean(R, s));
+    R->acc_dirty = true;               // until every kernel of this pass is enqueued
     for (int l = 3; l >= 1; --l) {
         if (hook && l == 2) KWS_TRY(hook->fire(5, s));
         const int C = kCh[l + 1];
@@ -799,7 +818,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         if (pool[l]) {
             const long NW = (long)B * (Hz[l] / 2) * (Wz[l] / 2);       // one thread per (pool window, channel)
             stat_grid(NW, C, nblk, rows);
-            if (compact_g && routed_bwd2)
+            if (l == 1 && acc_bn2) ;                            // done by conv3_group_dgrad_kernel's epilogue
+            else if (compact_g && routed_bwd2)
                 KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_routed_kernel, dim3(nblk), dim3(256), 0, s, w.zmax2, w.da[1], k, NW, C,
                            rows, w.partial);
             else if (compact_g)
@@ -818,9 +838,12 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                        rows, w.partial, rate, slo, shi);
         // conv2's early weight gradient forks right behind this finalize kernel
         const bool wgrad_early_l1 = compact_g && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
-        if (l == 1 && wgrad_early_l1) arm(1);
-        KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
-                   grads + m->o_g[l], grads + m->o_b[l], k);
+        if (l == 1 && acc_bn2) ;                                // the consumers derive k2 / k3 themselves; fork(1) was armed in front of conv3's data gradient
+        else {
+            if (l == 1 && wgrad_early_l1) arm(1);
+            KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
+                       grads + m->o_g[l], grads + m->o_b[l], k);
+        }
         if (l != 1) arm(l);                                 // the apply kernel below is the last one in front of fork(l)
         if (l == 1)
             ;                                                   // fused into conv_dgrad_clip's staging below
@@ -852,8 +875,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             // (the caller's stream does not wait for the conv4 wgrad, and the collective runs under the rest of the backward pass).
             if (comm) KWS_TRY(comm_allreduce_early(comm, grads + m->o_k[3], m->P - m->o_k[3], s2));
             if (bucket_event) KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
-            if (mprec == 1 && group_fwd_ok(m) && (long)blocks_for(B, kFuClips) <= kStatStride) {
-                // the clip-group form (the forward pass prepared the weights for it: same predicate as cnn_forward's group_fwd)
+            if (group_bwd) {
                 fused_bn3_blocks = launch_group_dgrad4(m, B, w, s);
                 if (fused_bn3_blocks < 0) return fused_bn3_blocks;
             } else if (mprec == 1 && blocks_for((long)B * Hs[3] * Ws[3], 64) <= (unsigned)kStatStride) {
@@ -870,7 +892,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const ConvGeom g = geom3x3(B, Hs[2], Ws[2], 2);
             if (mprec == 1) KWS_TRY(launch_wgrad_bf16<32, 64, 3>(in, w.gz[2], dk, g, s2, nullptr, det));
             else KWS_TRY(launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2, det));
-            if (mprec == 1 && group_fwd_ok(m) && (long)blocks_for(B, kFuClips) <= kStatStride) KWS_TRY(launch_group_dgrad3(m, B, w, s));
+            if (group_bwd) {
+                if (acc_bn2) arm(1);                            // the last kernel in front of conv2's early weight-gradient fork
+                KWS_TRY(launch_group_dgrad3(m, B, w, s, acc_bn2 ? acc_set(R, 1, 1, par) : nullptr));
+            }
             else KWS_TRY(launch_dgrad<64, 32, 2>(w.gz[2], kern, w.da[1], g, s));
         } else {
             // conv2 (16 -> 32, 3x3, stride 1): clip-resident kernels, the clip's tiles are staged in LDS once
@@ -884,6 +909,13 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const size_t smd = sizeof(float) * (size_t)(H1 + 2) * (W1 + 2) * (32 + 4);
             BnBwdArgs bn = {w.z[1], params + m->o_g[1], k.mean, k.inv, k.k2, k.k3};
             if (compact_g) { bn.gw = w.da[1]; bn.arg = routed_bwd2 ? w.arg2 : reinterpret_cast<const unsigned char *>(w.da[2]); }
+            BnBwdArgs bn_w = bn;                                // the weight gradient's copy: it only reads the accumulator set
+            if (acc_bn2) {
+                bn.acc = bn_w.acc = acc_set(R, 1, 1, par);
+                bn.M = bn_w.M = M;
+                bn.acc_clear_set = acc_set(R, 1, 1, par + 1);
+                bn.dgamma = grads + m->o_g[1]; bn.dbeta = grads + m->o_b[1]; bn.k2w = k.k2; bn.k3w = k.k3;
+            }
             const bool wgrad_bf16 = mprec == 1 && H1 * W1 <= 160;
             // compact g and a clip that fits the kernels' register staging: the weight gradient forms dz itself (from the routed g
             // and z2), so it forks BEFORE the data gradient and runs beside it and beside layer 1 on the side stream; the data
@@ -897,7 +929,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                 if (int rc = fork(1)) return rc;
                 static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel<true>, 256, smwb);
                 if (!no_arm) arm_stop_event(R->ev[9], s2);       // the last kernel of the side stream: its completion is the join event
-                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel<true>, wgrad_grid(occ), dim3(256), smwb, s2, in, nullptr, dk, B, H1, W1, bn);
+                KWS_LAUNCH("conv_wgrad_clip_bf16<16,32>", conv_wgrad_clip_bf16_kernel<true>, wgrad_grid(occ), dim3(256), smwb, s2, in, nullptr, dk, B, H1, W1, bn_w);
             }
             if (mprec == 1) {
                 // split-precision form: 2 blocks per CU by registers (the weight fragments of all nine taps stay in them)
@@ -961,6 +993,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     if (!stop_event_bound(R->ev[9])) KWS_HIP_CHECK(hipEventRecord(R->ev[9], s2));   // join: every wgrad is part of the caller's stream order again
     KWS_HIP_CHECK(hipStreamWaitEvent(s, R->ev[9], 0));
     KWS_LAUNCH_CHECK("simple_cnn backward");
+    R->acc_dirty = false;
     return KWS_OK;
 }
 
@@ -1244,6 +1277,12 @@ kws::ModelRes *kws_model::dev_res()
         if (hipStreamCreateWithPriority(&r.side, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); r.side = nullptr; return nullptr; }
         for (auto &e : r.ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        const size_t acc_bytes = sizeof(double) * 2 * 4 * 2 * kws::kAccDoubles;
+        if (hipMalloc(reinterpret_cast<void **>(&r.acc), acc_bytes) != hipSuccess || hipMemsetAsync(r.acc, 0, acc_bytes, r.side) != hipSuccess ||
+            hipStreamSynchronize(r.side) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
     }
     return &r;
 }
@@ -1257,6 +1296,7 @@ kws_model::~kws_model()
         for (auto &e : kv.second.ev)
             if (e) (void)hipEventDestroy(e);
         if (kv.second.side) (void)hipStreamDestroy(kv.second.side);
+        if (kv.second.acc) (void)hipFree(kv.second.acc);
     }
     if (have && !res.empty()) (void)hipSetDevice(cur);
     (void)hipGetLastError();

@@ -23,6 +23,11 @@ struct Tensor {
 struct ModelRes {
     hipStream_t side = nullptr;
     hipEvent_t ev[16] = {nullptr};
+    // BatchNorm sum accumulators of the finalize-free train step (kws_device.h: acc_add): [pass 0 = forward, 1 = backward][layer 0..3]
+    // [parity][kAccDoubles] doubles, zero at creation; a pass uses the sets of its parity and clears the other one
+    double *acc = nullptr;
+    unsigned fwd_passes = 0, bwd_passes = 0;
+    bool acc_dirty = false;             // an enqueue failed half-way: clear everything before the next pass
 };
 
 struct CnnDims { int H0, W0, H1, W1, H2, W2, H3, W3, H4, W4, flat; };

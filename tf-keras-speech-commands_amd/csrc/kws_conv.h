@@ -1323,17 +1323,25 @@ struct BnBwdArgs {
     long M = 1;
     float *dgamma = nullptr, *dbeta = nullptr, *k2w = nullptr, *k3w = nullptr;
 };
-// k2 / k3 of this thread's channels 4 c4 .. 4 c4 + 3 (of C) from the accumulator set; `writer`: this thread also leaves the finalize outputs
+// k2 / k3 of this thread's channels 4 c4 .. 4 c4 + 3 (of C <= 64) from the accumulator set: the first 2 C threads of the block sum one
+// value each (eight loads), the block shares them through LDS (contains a barrier: every thread of the block calls it); `writer`: this
+// block also leaves the finalize outputs
 __device__ __forceinline__ void bn_bwd_k_from_acc(const BnBwdArgs &bn, int C, int c4, bool writer, float *k2, float *k3)
 {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int c = 4 * c4 + e;
-        const double s = acc_sum(bn.acc, 2 * C, c), sx = acc_sum(bn.acc, 2 * C, C + c);
-        k2[e] = (float)(s / (double)bn.M);
-        k3[e] = (float)(sx / (double)bn.M);
-        if (writer) { bn.dbeta[c] = (float)s; bn.dgamma[c] = (float)sx; bn.k2w[c] = k2[e]; bn.k3w[c] = k3[e]; }
+    __shared__ float kk[128];
+    const int i = threadIdx.x;
+    if (i < 2 * C) {
+        const double t = acc_sum(bn.acc, 2 * C, i);
+        const float kv = (float)(t / (double)bn.M);
+        kk[i] = kv;
+        if (writer) {
+            if (i < C) { bn.dbeta[i] = (float)t; bn.k2w[i] = kv; }
+            else { bn.dgamma[i - C] = (float)t; bn.k3w[i - C] = kv; }
+        }
     }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { k2[e] = kk[4 * c4 + e]; k3[e] = kk[C + 4 * c4 + e]; }
 }
 template <int CR, bool BN>
 __global__ __launch_bounds__(256) void conv_dgrad_clip_kernel(float *__restrict__ dz, const float *__restrict__ wgt,
@@ -1481,8 +1489,7 @@ __global__ __launch_bounds__(256, 2) void conv_dgrad_clip_bf16_kernel(float *__r
             if (!bn.acc) { k2[e] = bn.k2[c]; k3[e] = bn.k3[c]; }
         }
         if (bn.acc) {
-            const bool writer = bn.dgamma && blockIdx.x == 0 && (int)threadIdx.x < F4;
-            bn_bwd_k_from_acc(bn, 4 * F4, threadIdx.x % F4, writer, k2, k3);
+            bn_bwd_k_from_acc(bn, 4 * F4, threadIdx.x % F4, bn.dgamma && blockIdx.x == 0, k2, k3);
             if (bn.acc_clear_set && blockIdx.x == 0) acc_clear(bn.acc_clear_set, threadIdx.x, 256);
         }
     }

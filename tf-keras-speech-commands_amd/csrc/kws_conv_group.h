@@ -56,30 +56,46 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_fwd_kernel(GroupCon
     bf16x8 b3[3][3];
     fu_load_b(g.f3, ct, lane, b3[0]);
     fu_load_b(g.f3, 4 + ct, lane, b3[1]);
-    {
-        constexpr int PER = kFuH2 * kFuW2 * kFuC2 / 4;
-        for (int i = tid; i < kFuClips * PER; i += kGrThreads) {
-            const int c = i / PER, r = i - c * PER, px = r >> 3, u = r & 7;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b0 + c < g.B) {
-                if (g.z2) {
-                    const int ph = px / kFuW2, pw = px - ph * kFuW2;
-                    const float *zp = g.z2 + ((((long)(b0 + c) * kGrH1 + 2 * ph) * kGrW1 + 2 * pw) * kFuC2 + 4 * u);
-                    const f32x4 z0 = *reinterpret_cast<const f32x4 *>(zp), z1 = *reinterpret_cast<const f32x4 *>(zp + kFuC2);
-                    const f32x4 z2v = *reinterpret_cast<const f32x4 *>(zp + kGrW1 * kFuC2), z3v = *reinterpret_cast<const f32x4 *>(zp + kGrW1 * kFuC2 + kFuC2);
-                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(g.sc2 + 4 * u), sh = *reinterpret_cast<const f32x4 *>(g.sh2 + 4 * u);
+    constexpr int PER = kFuH2 * kFuW2 * kFuC2 / 4;
+    if (g.z2) {
+        // three items per thread in flight: the twelve window loads of a batch are issued before its first store (a global store may alias
+        // a later load for the compiler, and one load -> store round trip per item was 10 us of this kernel)
+        static_assert(kGrThreads % 8 == 0, "a thread's channel quad is the same for all of its items");
+        const int u = tid & 7;
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>(g.sc2 + 4 * u), sh = *reinterpret_cast<const f32x4 *>(g.sh2 + 4 * u);
+        constexpr int NB = 3, NIT = (kFuClips * PER + kGrThreads - 1) / kGrThreads;
+#pragma unroll
+        for (int base = 0; base < NIT; base += NB) {
+            f32x4 z[NB][4];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int i = tid + (base + k) * kGrThreads, c = i / PER, r = i - c * PER, px = r >> 3;
+                const int ph = px / kFuW2, pw = px - ph * kFuW2;
+                const bool ok = i < kFuClips * PER && b0 + c < g.B;
+                const float *zp = g.z2 + ((((long)(b0 + c) * kGrH1 + 2 * ph) * kGrW1 + 2 * pw) * kFuC2 + 4 * u);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    z[k][j] = ok ? *reinterpret_cast<const f32x4 *>(zp + ((j >> 1) * kGrW1 + (j & 1)) * kFuC2) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int i = tid + (base + k) * kGrThreads, c = i / PER, r = i - c * PER, px = r >> 3;
+                if (i >= kFuClips * PER) continue;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (b0 + c < g.B) {
                     f32x4 zm;
                     unsigned am = 0u;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float y0 = fmaf(z0[e], sc[e], sh[e]), y1 = fmaf(z1[e], sc[e], sh[e]), y2 = fmaf(z2v[e], sc[e], sh[e]), y3 = fmaf(z3v[e], sc[e], sh[e]);
+                        const float y0 = fmaf(z[k][0][e], sc[e], sh[e]), y1 = fmaf(z[k][1][e], sc[e], sh[e]);
+                        const float y2 = fmaf(z[k][2][e], sc[e], sh[e]), y3 = fmaf(z[k][3][e], sc[e], sh[e]);
                         v[e] = relu6f(fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
                         unsigned arg = 0u;                   // first maximum of relu6(y): the element the backward pass routes the gradient to
-                        float best = relu6f(y0), zz = z0[e];
+                        float best = relu6f(y0), zz = z[k][0][e];
                         const float v1 = relu6f(y1), v2 = relu6f(y2), v3 = relu6f(y3);
-                        if (v1 > best) { best = v1; arg = 1u; zz = z1[e]; }
-                        if (v2 > best) { best = v2; arg = 2u; zz = z2v[e]; }
-                        if (v3 > best) { arg = 3u; zz = z3v[e]; }
+                        if (v1 > best) { best = v1; arg = 1u; zz = z[k][1][e]; }
+                        if (v2 > best) { best = v2; arg = 2u; zz = z[k][2][e]; }
+                        if (v3 > best) { arg = 3u; zz = z[k][3][e]; }
                         zm[e] = zz;
                         am |= arg << (8 * e);
                     }
@@ -87,9 +103,15 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_fwd_kernel(GroupCon
                     *reinterpret_cast<f32x4 *>(g.a2w + o) = v;
                     *reinterpret_cast<f32x4 *>(g.zmax2 + o) = zm;
                     *reinterpret_cast<unsigned *>(g.arg2 + o) = am;
-                } else
-                    v = *reinterpret_cast<const f32x4 *>(g.a2 + ((long)(b0 + c) * PER + r) * 4);
+                }
+                *reinterpret_cast<f32x4 *>(A2 + ((px * kFuClips + c) * 8 + (u ^ ((c >> 1) & 7))) * 4) = v;
             }
+        }
+    } else {
+        for (int i = tid; i < kFuClips * PER; i += kGrThreads) {
+            const int c = i / PER, r = i - c * PER, px = r >> 3, u = r & 7;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b0 + c < g.B) v = *reinterpret_cast<const f32x4 *>(g.a2 + ((long)(b0 + c) * PER + r) * 4);
             *reinterpret_cast<f32x4 *>(A2 + ((px * kFuClips + c) * 8 + (u ^ ((c >> 1) & 7))) * 4) = v;
         }
     }
@@ -271,6 +293,14 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_dgrad_kernel(GroupD
     const int ch = 16 * ct + li;
     const float gsc = g.coef[ch], gsh = g.coef[kFuC3 + ch], gmean = g.coef[2 * kFuC3 + ch], ginv = g.coef[3 * kFuC3 + ch];
     float s = 0.f, ss = 0.f;
+    float z3v[NP][4];                        // every load is issued before the first store (the stores may alias them for the compiler)
+#pragma unroll
+    for (int q = 0; q < NP; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int clip = 4 * lq + r;
+            z3v[q][r] = b0 + clip < g.B ? g.z3[((long)(b0 + clip) * (kFuH3 * kFuW3) + NP * grp + q) * kFuC3 + ch] : 0.f;
+        }
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         const int pos = NP * grp + q;
@@ -279,7 +309,7 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_dgrad_kernel(GroupD
             const int clip = 4 * lq + r;
             if (b0 + clip < g.B) {
                 const long e = ((long)(b0 + clip) * (kFuH3 * kFuW3) + pos) * kFuC3 + ch;
-                const float zv = g.z3[e], yv = fmaf(zv, gsc, gsh);
+                const float zv = z3v[q][r], yv = fmaf(zv, gsc, gsh);
                 const float v = (yv > 0.f && yv < 6.f) ? acc[q][r] : 0.f;
                 g.g3[e] = v;
                 s += v; ss = fmaf(v, (zv - gmean) * ginv, ss);
@@ -355,6 +385,14 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_dgrad_kernel(GroupD
     if (g.acc) {
         const float gsc = g.coef2[ch], gsh = g.coef2[kFuC2 + ch], gmean = g.coef2[2 * kFuC2 + ch], ginv = g.coef2[3 * kFuC2 + ch];
         float s = 0.f, sx = 0.f;
+        float za[NP][4];                     // every load is issued before the first store (the stores may alias them for the compiler)
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pos = NP * grp + q, clip = 4 * lq + r;
+                za[q][r] = (pos < NPOS && b0 + clip < g.B) ? g.zmax2[((long)(b0 + clip) * NPOS + pos) * kFuC2 + ch] : 0.f;
+            }
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int pos = NP * grp + q;
@@ -364,10 +402,10 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_dgrad_kernel(GroupD
                     const int clip = 4 * lq + r;
                     if (b0 + clip < g.B) {
                         const long e = ((long)(b0 + clip) * NPOS + pos) * kFuC2 + ch;
-                        const float za = g.zmax2[e], ya = fmaf(za, gsc, gsh);
+                        const float ya = fmaf(za[q][r], gsc, gsh);
                         const float v = (ya > 0.f && ya < 6.f) ? acc[q][r] : 0.f;
                         g.da2[e] = v;
-                        s += v; sx = fmaf(v, (za - gmean) * ginv, sx);
+                        s += v; sx = fmaf(v, (za[q][r] - gmean) * ginv, sx);
                     }
                 }
         }

@@ -650,7 +650,7 @@ def test_overlap_point_changes_scheduling_only(torch):
     dm.train_fwd_bwd(x, y, dropout_seed=3)
     torch.cuda.synchronize()
     want = dm.grads.clone()
-    for point in (0, 1, 2, 3, 4, 5, 6, 7, -1):
+    for point in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, -1):
         dm.set_overlap_point(point)
         calls = []
         ev = torch.cuda.Event()
@@ -659,7 +659,7 @@ def test_overlap_point_changes_scheduling_only(torch):
         assert calls == [1] and ev.query(), point
         assert torch.equal(dm.grads, want), point
     with pytest.raises(L.KwsError):
-        dm.set_overlap_point(8)
+        dm.set_overlap_point(11)
 
 
 @pytest.mark.parametrize("model_type", ["simple_cnn", "simple_cnn_lite", "simple_gru"])

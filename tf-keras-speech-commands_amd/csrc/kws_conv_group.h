@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_fwd_kernel(GroupCon
 // output channels (36 k-steps), 64 columns.  The epilogue is BatchNorm-3's backward reduction (conv3 has no pooling): g = da3 gated by
 // ReLU6(BN3(z3)), stored, and the per-block sums of g and g xhat -- the contract of conv_bf16_kernel<128, 64, MODE_DGRAD, EPI_BNBWD_GATE6>.
 constexpr int kGrD4P = kFuH3 * kFuW3 * kFuClips * kFuC4;                        // bf16 per plane of the staged dz4
-struct GroupDgrad4Args { const __bf16 *dz[3], *fw[3]; const float *z3, *coef; float *g3; double *partial; int stride, B; };
+struct GroupDgrad4Args { const __bf16 *dz[3], *fw[3]; const float *z3, *coef; float *g3; double *partial; int stride, B; double *acc; };
 
 __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_dgrad_kernel(GroupDgrad4Args g)
 {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_dgrad_kernel(GroupD
         }
     }
     __syncthreads();
-    group_stats<kFuC3, kGrWaves / 4>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride);
+    group_stats<kFuC3, kGrWaves / 4>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride, g.acc);
 }
 
 // conv3's DATA gradient (3x3, stride 2): da2(y, x) = sum over the taps with y + 1 - kh and x + 1 - kw even and inside the 4 x 3 map of

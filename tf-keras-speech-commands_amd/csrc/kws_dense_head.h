@@ -23,6 +23,13 @@ struct DenseHeadArgs {
     float *dw2, *db2, *ddb;           // gradients: head kernel / bias, Dense bias (float atomics)
     int B, C, flat;
     HeadFwdArgs fw;
+    // acc4 != nullptr: the epilogue is ALSO BatchNorm-4's backward reduction over the routed elements (what bn_bwd_reduce_routed_full_kernel
+    // did from da4, kws_layers.h): da4 leaves as the dropped, ReLU6-gated gradient per (pool window, channel) -- the compact form
+    // bn_bwd_apply_routed_planes_kernel expands -- and the block's sums of g and g xhat go to the accumulator set (kws_device.h: acc_add)
+    const float *zmax4 = nullptr, *coef4 = nullptr;               // z4 at the routed element; BN4's scale | shift | mean | inv (128 each)
+    double *acc4 = nullptr;
+    float drop_rate = 0.f;
+    uint32_t seed_lo = 0, seed_hi = 0;
 };
 
 __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
@@ -178,17 +185,50 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
             const float *row = dd + li * kDhKS + 32 * kk + 8 * lq;          // natural k order (ofrag planes): one unit of 8 floats
             fu_split(*reinterpret_cast<const f32x4 *>(row), *reinterpret_cast<const f32x4 *>(row + 4), a[kk]);
         }
+        float za[4] = {0.f, 0.f, 0.f, 0.f}, zan[4] = {0.f, 0.f, 0.f, 0.f};     // acc4: zmax4 of this / the next tile (loaded ahead of the stores)
+        if (g.acc4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (b0 + 4 * lq + r < g.B) za[r] = g.zmax4[(long)(b0 + 4 * lq + r) * g.flat + 16 * wave + li];
         for (int i = 0; i < tpw; ++i) {
             const int nt = wave + 4 * i, tap = nt / (kDhK / 16), ctl = nt - tap * (kDhK / 16);   // flat column tile -> (tap, 16-channel tile)
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             bf16x8 b[4][3];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) fu_load_b(g.fo, (long)(tap * 4 + kk) * (kDhK / 16) + ctl, lane, b[kk]);
+            if (g.acc4 && i + 1 < tpw)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (b0 + 4 * lq + r < g.B) zan[r] = g.zmax4[(long)(b0 + 4 * lq + r) * g.flat + 16 * (nt + 4) + li];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc = mfma_bf16x6(a[kk], b[kk], acc);
+            if (g.acc4) {
+                // flat index = (pool window) * 128 + channel: dropout mask, ReLU6 gate on y = BN4(z of the routed element), sums
+                const int ch = 16 * ctl + li;
+                const float gsc = g.coef4[ch], gsh = g.coef4[kDhK + ch], gmean = g.coef4[2 * kDhK + ch], ginv = g.coef4[3 * kDhK + ch];
+                float s = 0.f, sx = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (b0 + 4 * lq + r < g.B) g.da4[(long)(b0 + 4 * lq + r) * g.flat + 16 * nt + li] = acc[r];
+                for (int r = 0; r < 4; ++r)
+                    if (b0 + 4 * lq + r < g.B) {
+                        const long e = (long)(b0 + 4 * lq + r) * g.flat + 16 * nt + li;
+                        float v = acc[r];
+                        if (g.drop_rate > 0.f) v = dropout_keep(g.seed_lo, g.seed_hi, (uint32_t)e, g.drop_rate) ? v / (1.f - g.drop_rate) : 0.f;
+                        const float ya = fmaf(za[r], gsc, gsh);
+                        v = (ya > 0.f && ya < 6.f) ? v : 0.f;
+                        g.da4[e] = v;
+                        s += v; sx = fmaf(v, (za[r] - gmean) * ginv, sx);
+                    }
+                double sd = (double)s, sxd = (double)sx;
+                sd += __shfl_xor(sd, 16, 64); sd += __shfl_xor(sd, 32, 64);
+                sxd += __shfl_xor(sxd, 16, 64); sxd += __shfl_xor(sxd, 32, 64);
+                if (lq == 0) { acc_add(g.acc4, 2 * kDhK, ch, sd); acc_add(g.acc4, 2 * kDhK, kDhK + ch, sxd); }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) za[r] = zan[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (b0 + 4 * lq + r < g.B) g.da4[(long)(b0 + 4 * lq + r) * g.flat + 16 * nt + li] = acc[r];
+            }
         }
     }
     // gather the dense (K x C) block of dW2 in LDS so that the float atomics of a wave-instruction hit 64 contiguous addresses

@@ -468,6 +468,93 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_planes_kernel(const float *_
     reinterpret_cast<bf16x4 *>(out.p[2])[i4] = l;
 }
 
+// The accumulator form of the backward coefficients (kws_device.h: acc_add): the first 2 C threads of every block sum one value each,
+// k2 = sum g / M and k3 = sum g xhat / M go to `kk` (LDS, [2 C]); block 0 also leaves what bn_bwd_finalize_kernel wrote and clears the
+// set of the other parity.  Contains a barrier.
+struct BnAccBwd { const double *acc; double *acc_clear_set; long M; float *dgamma, *dbeta; };
+__device__ __forceinline__ void bn_bwd_k_prologue(const BnAccBwd &a, const BnCoef &k, int C, float *kk)
+{
+    const int i = threadIdx.x;
+    if (i < 2 * C) {
+        const double t = acc_sum(a.acc, 2 * C, i);
+        const float kv = (float)(t / (double)a.M);
+        kk[i] = kv;
+        if (blockIdx.x == 0) {
+            if (i < C) { a.dbeta[i] = (float)t; k.k2[i] = kv; }
+            else { a.dgamma[i - C] = (float)t; k.k3[i - C] = kv; }
+        }
+    }
+    if (blockIdx.x == 0 && a.acc_clear_set) acc_clear(a.acc_clear_set, threadIdx.x, blockDim.x);
+    __syncthreads();
+}
+
+// Layer 4 (pooled, split precision) from the COMPACT gradient: gq (B, H/2, W/2, C) holds the dropped, gated gradient of every pool window
+// (dense_head_fused_kernel's epilogue), arg the element it belongs to; every other element of z has g = 0.  Same arithmetic as
+// bn_bwd_apply_planes_kernel on the expanded g, without the z-sized fp32 g tensor in between; grid-stride, 256 threads, C <= 128.
+template <bool RELU_IN>
+__global__ __launch_bounds__(256) void bn_bwd_apply_routed_planes_kernel(const float *__restrict__ z, const float *__restrict__ gq,
+                                                                          const unsigned char *__restrict__ arg, BnCoef k,
+                                                                          const float *__restrict__ gamma, int B, int H, int W, int C,
+                                                                          BnAccBwd a, Bf16PlanesOut out)
+{
+    __shared__ float kk[256];
+    bn_bwd_k_prologue(a, k, C, kk);
+    const int Hp = H / 2, Wp = W / 2, C4 = C / 4;
+    const long total4 = (long)B * H * W * C4;
+    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * 256) {
+        const int c0 = (int)(i4 % C4) * 4;
+        const long pix = i4 / C4;
+        const int p = (int)(pix % ((long)H * W)), b = (int)(pix / ((long)H * W)), y = p / W, x = p - y * W, ph = y >> 1, pw = x >> 1;
+        const f32x4 zv = reinterpret_cast<const f32x4 *>(z)[i4];
+        f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+        if (ph < Hp && pw < Wp) {
+            const long q = (((long)b * Hp + ph) * Wp + pw) * C + c0;
+            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gq + q);
+            const unsigned a4 = *reinterpret_cast<const unsigned *>(arg + q), e = (unsigned)((y & 1) * 2 + (x & 1));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = ((a4 >> (8 * j)) & 0xffu) == e ? g4[j] : 0.f;
+        }
+        f32x4 d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            const float xhat = (zv[j] - k.mean[c]) * k.inv[c];
+            float v = gamma[c] * k.inv[c] * (gv[j] - kk[c] - xhat * kk[C + c]);
+            if (RELU_IN) v = zv[j] > 0.f ? v : 0.f;
+            d[j] = v;
+        }
+        bf16x4 h, m, l;
+        split_bf16(d, h, m, l);
+        reinterpret_cast<bf16x4 *>(out.p[0])[i4] = h;
+        reinterpret_cast<bf16x4 *>(out.p[1])[i4] = m;
+        reinterpret_cast<bf16x4 *>(out.p[2])[i4] = l;
+    }
+}
+
+// The accumulator form of bn_bwd_apply_kernel (layers without pooling: g is full-size, in place): grid-stride, 256 threads, C <= 128
+template <bool RELU_IN>
+__global__ __launch_bounds__(256) void bn_bwd_apply_acc_kernel(const float *__restrict__ z, float *__restrict__ gz, BnCoef k,
+                                                                const float *__restrict__ gamma, long total4, int C, BnAccBwd a)
+{
+    __shared__ float kk[256];
+    bn_bwd_k_prologue(a, k, C, kk);
+    const int C4 = C / 4;
+    for (long i4 = (long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * 256) {
+        const int c0 = (int)(i4 % C4) * 4;
+        const f32x4 zv = reinterpret_cast<const f32x4 *>(z)[i4], gv = reinterpret_cast<const f32x4 *>(gz)[i4];
+        f32x4 d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            const float xhat = (zv[j] - k.mean[c]) * k.inv[c];
+            float v = gamma[c] * k.inv[c] * (gv[j] - kk[c] - xhat * kk[C + c]);
+            if (RELU_IN) v = zv[j] > 0.f ? v : 0.f;
+            d[j] = v;
+        }
+        reinterpret_cast<f32x4 *>(gz)[i4] = d;
+    }
+}
+
 // ---- head: Dense(C, softmax) 'score_predict' (classifier/model.py:37) + loss (classifier/loss.py) --------------
 // block = 16 samples.  logits -> probs, per-sample loss / correct flag, dlogits = d(mean loss)/d(logits) * grad_scale
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float *__restrict__ d1, const float *__restrict__ w2,

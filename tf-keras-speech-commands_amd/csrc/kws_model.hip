@@ -220,7 +220,11 @@ int launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom
     constexpr size_t stage = (size_t)3 * 32 * 4 * (TPB * tr_row_words(CIN) + tr_row_words(COUT)), tile = (size_t)CIN * COUT * sizeof(float);
     constexpr size_t smem = stage > tile ? stage : tile;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>), (int)smem)) return rc;
-    static const int occ = resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>, 256, smem);
+    static const int occ0 = resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>, 256, smem);
+    int occ = occ0;
+#ifdef KWS_EXP
+    { const char *e = getenv(CIN == 64 ? "KWS_X_OCCW4" : "KWS_X_OCCW3"); if (e) occ = std::min(occ0, atoi(e)); }
+#endif
     const long M = (long)g.B * g.Ho * g.Wo, nchunk = (M + 31) / 32;
     const int ngroups = g.KH * g.KW / TPB;
     // ranges: a multiple of 8 (one per XCD), at most one resident round, at least 4 chunks per block
@@ -405,11 +409,12 @@ static int launch_group_dgrad3(const kws_model *m, int B, CnnWs &w, hipStream_t 
     KWS_LAUNCH("conv_group_dgrad<64,32>", conv3_group_dgrad_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(6 * kFuA3P), s, a);
     return KWS_OK;
 }
-static int launch_group_dgrad4(const kws_model *m, int B, CnnWs &w, hipStream_t s)
+static int launch_group_dgrad4(const kws_model *m, int B, CnnWs &w, hipStream_t s, double *acc3 = nullptr)
 {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv4_group_dgrad_kernel), 6 * kGrD4P)) return rc;
     GroupDgrad4Args a{};
     a.z3 = w.z[2]; a.coef = coef_of(w.coef[2], 64).scale; a.g3 = w.gz[2]; a.partial = w.partial; a.stride = kStatStride; a.B = B;
+    a.acc = acc3;                       // acc3: the sums go to the accumulator set, no finalize kernel follows
     for (int p = 0; p < 3; ++p) { a.dz[p] = w.dzp[p]; a.fw[p] = w.wsp[1][p]; }
     KWS_LAUNCH("conv_group_dgrad<128,64>", conv4_group_dgrad_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(6 * kGrD4P), s, a);
     return (int)blocks_for(B, kFuClips);
@@ -578,6 +583,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         else KWS_LAUNCH("l1_act_pool_kernel", l1_act_pool_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, k1.scale, k1.shift, w.a[0], B,
                    d.H0, d.W0, cpb);
     }
+    if (hook) KWS_TRY(hook->fire(8, s));                 // behind layer 1: the featurizer then shares the chip with the forward convolutions
     bool bound6 = false;
     const bool a3_on_load = cnn_a3_on_load(m, bf16, training);
     const bool routed_bwd2 = cnn_compact_g2(m, bf16);
@@ -649,6 +655,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                 if (fused_stat_blocks < 0) return fused_stat_blocks;
             } else KWS_TRY(launch_gemm<64, 128, MODE_FWD, EPI_RELU>(in, kern, nullptr, w.z[3], geom3x3(B, Hs[3], Ws[3], 1), s));
         }
+        if (hook && l < 3) KWS_TRY(hook->fire(8 + l, s));     // 9 behind conv2's forward, 10 behind conv3's
         BnCoef k = coef_of(w.coef[l], C);
         if (training) {
             int nblk, rows;
@@ -729,6 +736,19 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         KWS_HIP_CHECK(hipStreamWaitEvent(s2, R->ev[ev], 0));
         return KWS_OK;
     };
+    const bool routed_bwd2 = cnn_compact_g2(m, mprec == 1);      // the forward pass left zmax2 / arg2 (same predicate)
+    // the clip-group form of conv4's / conv3's data gradients (the forward pass prepared the weights for it: cnn_forward's group_fwd)
+    const bool group_bwd = mprec == 1 && group_fwd_ok(m) && (long)blocks_for(B, kFuClips) <= kStatStride;
+    // finalize-free BatchNorm backward (kws_device.h: acc_add), non-deterministic mode.  Layer 2: conv3's data gradient does the reduction
+    // in its epilogue and conv2's clip kernels derive k2 / k3 from the accumulator set.  Layer 3: conv4's data gradient adds its sums to the
+    // set and the apply kernel derives the coefficients.  Layer 4: the fused Dense + head kernel's epilogue is the reduction, the apply
+    // kernel expands the compact gradient.
+    const bool acc_bn2 = group_bwd && !det && routed_bwd2 && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
+    const bool acc_bn3 = group_bwd && !det;
+    const bool acc_bn4 = fused_head && dense_head_fused_ok(m, mprec) && !det && kCh[4] == kDhK && d.flat == d.H4 * d.W4 * kCh[4];
+    const unsigned par = R->bwd_passes++;
+    KWS_TRY(acc_make_clean(R, s));
+    R->acc_dirty = true;               // until every kernel of this pass is enqueued
     // head: dW2, db2, dd1 (gated by dense's ReLU6)
     {
         // the MFMA head kernel also leaves the dense bias gradient (column sums of dd1) and the loss / accuracy sums
@@ -745,6 +765,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             for (int p = 0; p < 3; ++p) { da.fd[p] = w.wsp[2][3 + p]; da.fo[p] = w.wsp[2][p]; }
             da.d1 = w.d1; da.dd1 = w.dd1; da.da4 = w.da4; da.dw2 = grads + m->o_hk; da.db2 = grads + m->o_hb; da.ddb = grads + m->o_db;
             da.B = B; da.C = m->C; da.flat = d.flat;
+            if (acc_bn4) {
+                da.zmax4 = w.zmax4; da.coef4 = coef_of(w.coef[3], 128).scale; da.acc4 = acc_set(R, 1, 3, par);
+                da.drop_rate = seed != 0 ? 0.5f : 0.f; da.seed_lo = slo; da.seed_hi = shi;
+            }
             da.fw = HeadFwdArgs{params + m->o_hb, a->labels, a->class_weights, a->probs, w.loss_i, w.correct_i, a->grad_scale / (float)B, a->ignore_index};
             const size_t smem = sizeof(float) * (size_t)(16 * (d.flat + 8) + 2 * 16 * kDhKS + 16 * kDhCS + kDhK * kDhCS);
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(dense_head_fused_kernel), (int)smem)) return rc;
@@ -792,15 +816,6 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         if (hook) KWS_TRY(hook->fire(3, s));
     }
     int fused_bn3_blocks = 0;          // > 0: conv4's data gradient already did layer 3's BatchNorm-backward reduction
-    const bool routed_bwd2 = cnn_compact_g2(m, mprec == 1);      // the forward pass left zmax2 / arg2 (same predicate)
-    // the clip-group form of conv4's / conv3's data gradients (the forward pass prepared the weights for it: cnn_forward's group_fwd)
-    const bool group_bwd = mprec == 1 && group_fwd_ok(m) && (long)blocks_for(B, kFuClips) <= kStatStride;
-    // finalize-free BatchNorm backward (kws_device.h: acc_add), non-deterministic mode: conv3's data gradient does layer 2's reduction in
-    // its epilogue and conv2's clip kernels derive k2 / k3 from the accumulator set
-    const bool acc_bn2 = group_bwd && !det && routed_bwd2 && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
-    const unsigned par = R->bwd_passes++;
-    KWS_TRY(acc_make_clean(R, s));
-    R->acc_dirty = true;               // until every kernel of this pass is enqueued
     for (int l = 3; l >= 1; --l) {
         if (hook && l == 2) KWS_TRY(hook->fire(5, s));
         const int C = kCh[l + 1];
@@ -819,6 +834,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const long NW = (long)B * (Hz[l] / 2) * (Wz[l] / 2);       // one thread per (pool window, channel)
             stat_grid(NW, C, nblk, rows);
             if (l == 1 && acc_bn2) ;                            // done by conv3_group_dgrad_kernel's epilogue
+            else if (l == 3 && acc_bn4) ;                       // done by dense_head_fused_kernel's epilogue
             else if (compact_g && routed_bwd2)
                 KWS_LAUNCH(prof_name("bn_bwd_reduce_pool_kernel", l + 1), bn_bwd_reduce_routed_kernel, dim3(nblk), dim3(256), 0, s, w.zmax2, w.da[1], k, NW, C,
                            rows, w.partial);
@@ -838,7 +854,9 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                        rows, w.partial, rate, slo, shi);
         // conv2's early weight gradient forks right behind this finalize kernel
         const bool wgrad_early_l1 = compact_g && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
-        if (l == 1 && acc_bn2) ;                                // the consumers derive k2 / k3 themselves; fork(1) was armed in front of conv3's data gradient
+        const bool acc_l = (l == 1 && acc_bn2) || (l == 2 && acc_bn3 && fused_bn3_blocks > 0) || (l == 3 && acc_bn4);
+        const BnAccBwd ab{acc_set(R, 1, l, par), acc_set(R, 1, l, par + 1), M, grads + m->o_g[l], grads + m->o_b[l]};
+        if (acc_l) ;                                            // the consumers derive k2 / k3 themselves (layer 2: fork(1) was armed in front of conv3's data gradient)
         else {
             if (l == 1 && wgrad_early_l1) arm(1);
             KWS_LAUNCH(prof_name("bn_bwd_finalize_kernel", l + 1), bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, w.partial, nblk, M, C, params + m->o_g[l],
@@ -847,6 +865,12 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         if (l != 1) arm(l);                                 // the apply kernel below is the last one in front of fork(l)
         if (l == 1)
             ;                                                   // fused into conv_dgrad_clip's staging below
+        else if (l == 3 && acc_bn4)
+            KWS_LAUNCH(prof_name("bn_bwd_apply_planes_kernel", l + 1), bn_bwd_apply_routed_planes_kernel<true>, dim3(std::min<unsigned>(1024u, blocks_for(M * C / 4, 256))),
+                       dim3(256), 0, s, w.z[l], w.da4, w.arg4, k, params + m->o_g[l], B, Hz[l], Wz[l], C, ab, (Bf16PlanesOut{{w.dzp[0], w.dzp[1], w.dzp[2]}}));
+        else if (l == 2 && acc_l)
+            KWS_LAUNCH(prof_name("bn_bwd_apply_kernel", l + 1), bn_bwd_apply_acc_kernel<false>, dim3(std::min<unsigned>(1024u, blocks_for(M * C / 4, 256))), dim3(256), 0, s,
+                       w.z[l], w.gz[l], k, params + m->o_g[l], M * C / 4, C, ab);
         else if (l == 3 && mprec == 1)
             // split precision: dz4 leaves as bf16 h/m/l planes, which is what both of its consumers stage (no fp32 dz4)
             KWS_LAUNCH(prof_name("bn_bwd_apply_planes_kernel", l + 1), bn_bwd_apply_planes_kernel<true>, dim3(blocks_for(M * C / 4, 256)), dim3(256), 0, s,
@@ -876,7 +900,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (comm) KWS_TRY(comm_allreduce_early(comm, grads + m->o_k[3], m->P - m->o_k[3], s2));
             if (bucket_event) KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
             if (group_bwd) {
-                fused_bn3_blocks = launch_group_dgrad4(m, B, w, s);
+                fused_bn3_blocks = launch_group_dgrad4(m, B, w, s, acc_bn3 ? acc_set(R, 1, 2, par) : nullptr);
                 if (fused_bn3_blocks < 0) return fused_bn3_blocks;
             } else if (mprec == 1 && blocks_for((long)B * Hs[3] * Ws[3], 64) <= (unsigned)kStatStride) {
                 // the data gradient's epilogue is BatchNorm 3's backward reduction (conv3 has no pooling): it gates by ReLU6(y3), stores
@@ -924,7 +948,11 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const size_t smwb = std::max((size_t)3 * 32 * (H1 + 2) * (W1 + 2) + (size_t)6 * 32 * (H1 * W1 + 1), sizeof(float) * 9 * 16 * 32);
             // two blocks per CU although three fit: the third takes the LDS the layer-1 kernels of the main chain need beside it
             // (same-box A/B: 0.785 ms/step with one or two, 0.800 with three); deterministic: one persistent block walks every clip
-            auto wgrad_grid = [&](int occ) { return dim3(det ? 1u : even_grid(cu_count() * std::min(occ, 2))); };
+            int wg2_cap = 2, dg2_cap = 2;
+#ifdef KWS_EXP
+            { const char *e = getenv("KWS_X_OCCW2"); if (e) wg2_cap = atoi(e); e = getenv("KWS_X_OCCD2"); if (e) dg2_cap = atoi(e); }
+#endif
+            auto wgrad_grid = [&](int occ) { return dim3(det ? 1u : even_grid(cu_count() * std::min(occ, wg2_cap))); };
             if (wgrad_early) {
                 if (int rc = fork(1)) return rc;
                 static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel<true>, 256, smwb);
@@ -935,7 +963,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                 // split-precision form: 2 blocks per CU by registers (the weight fragments of all nine taps stay in them)
                 const size_t smdb = (size_t)12 * 16 * (((H1 + 2) * (W1 + 2) + 15) & ~15);
                 if (wgrad_early)
-                    KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true, false>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s,
+                    KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true, false>), dim3(even_grid(cu_count() * dg2_cap)), dim3(256), smdb, s,
                                w.gz[1], kern, w.da[0], B, H1, W1, bn);
                 else if (compact_g)
                     KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s,
@@ -1392,7 +1420,7 @@ int kws_model_get_precision(const kws_model *m, int *matrix, int *infer)
 int kws_model_set_overlap_point(kws_model *m, int point)
 {
     if (!m) return fail(KWS_ERR_INVALID, "null argument");
-    if (point < -1 || point > 7) return fail(KWS_ERR_INVALID, "overlap point %d outside -1 .. 7", point);
+    if (point < -1 || point > 10) return fail(KWS_ERR_INVALID, "overlap point %d outside -1 .. 10", point);
     m->overlap_point = point;
     return KWS_OK;
 }

@@ -3,7 +3,7 @@ import json, os, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 for r in range(rounds):
-    for pt in (-1, 0, 6, 7, 1, 2, 3, 4, 5):
+    for pt in (-1, 8, 9, 10, 0, 6, 1, 2, 3, 4, 5):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "300", "--no-cpu-baseline", "--no-extra", "--profile-steps", "0",
                               "--overlap-point", str(pt)], capture_output=True, text=True, timeout=600)
         try:

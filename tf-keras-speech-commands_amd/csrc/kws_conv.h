@@ -1175,8 +1175,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_clip_bf16_kernel(const float 
                                                                      float *__restrict__ z, int B, int H, int W,
                                                                      double *__restrict__ partial, int partial_stride,
                                                                      const float *__restrict__ scale = nullptr,
-                                                                     const float *__restrict__ shift = nullptr)
+                                                                     const float *__restrict__ shift = nullptr, double *__restrict__ acc_out = nullptr)
 {
+    // acc_out != nullptr (STATS): the block's sums are added to that accumulator set (kws_device.h: acc_add), no finalize kernel follows
     constexpr int CIN = 16, COUT = 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char ctile[];   // [3 planes][2 halves][(H+2)(W+2)][8 bf16], zero halo
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), li = lane & 15, lq = lane >> 4;
@@ -1300,7 +1301,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_clip_bf16_kernel(const float 
         __syncthreads();
         if (threadIdx.x < 2 * COUT) {
             const int which = threadIdx.x / COUT, c = threadIdx.x % COUT, n = c / 16, l = c % 16;
-            partial[((long)which * COUT + c) * partial_stride + blockIdx.x] = red[(n * 2 + which) * 16 + l] + red[((n + 2) * 2 + which) * 16 + l];
+            const double v = red[(n * 2 + which) * 16 + l] + red[((n + 2) * 2 + which) * 16 + l];
+            if (acc_out) acc_add(acc_out, 2 * COUT, threadIdx.x, v);
+            else partial[((long)which * COUT + c) * partial_stride + blockIdx.x] = v;
         }
     }
 }

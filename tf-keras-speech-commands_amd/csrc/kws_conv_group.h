@@ -40,8 +40,10 @@ __device__ __forceinline__ void group_stats(float s, float ss, int ch, int grp, 
 // staged and written to `a2w` for the backward pass together with the routed element of every window (zmax2: its pre-BatchNorm value,
 // arg2: its index 0..3, first maximum of relu6(y): the contract of bn_act_pool_kernel<true>, kws_layers.h), so that kernel's launch and
 // the a2 round trip (18 MB each way) are gone.
+// in.acc != nullptr (with z2): BatchNorm-2's scale / shift come from the accumulator set conv2's forward added to (kws_layers.h:
+// bn_fwd_coef_prologue) instead of sc2 / sh2; acc != nullptr: this kernel's own sums go to an accumulator set instead of `partial`.
 struct GroupConv3Args { const float *a2; const __bf16 *f3[3]; float *z3; double *partial; int stride, B;
-                        const float *z2, *sc2, *sh2; float *a2w, *zmax2; unsigned char *arg2; };
+                        const float *z2, *sc2, *sh2; float *a2w, *zmax2; unsigned char *arg2; BnAccFwd in; double *acc; };
 constexpr int kGrH1 = 2 * kFuH2 + 1, kGrW1 = 2 * kFuW2;                         // conv2's map: 15 x 10 (the last row falls out of the 'valid' pooling)
 
 __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_fwd_kernel(GroupConv3Args g)
@@ -62,7 +64,14 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_fwd_kernel(GroupCon
         // a later load for the compiler, and one load -> store round trip per item was 10 us of this kernel)
         static_assert(kGrThreads % 8 == 0, "a thread's channel quad is the same for all of its items");
         const int u = tid & 7;
-        const f32x4 sc = *reinterpret_cast<const f32x4 *>(g.sc2 + 4 * u), sh = *reinterpret_cast<const f32x4 *>(g.sh2 + 4 * u);
+        __shared__ __attribute__((aligned(16))) float cf2[2 * kFuC2];
+        f32x4 sc, sh;
+        if (g.in.acc) {
+            bn_fwd_coef_prologue(g.in, kFuC2, cf2, cf2 + kFuC2);
+            sc = *reinterpret_cast<const f32x4 *>(cf2 + 4 * u); sh = *reinterpret_cast<const f32x4 *>(cf2 + kFuC2 + 4 * u);
+        } else {
+            sc = *reinterpret_cast<const f32x4 *>(g.sc2 + 4 * u); sh = *reinterpret_cast<const f32x4 *>(g.sh2 + 4 * u);
+        }
         constexpr int NB = 3, NIT = (kFuClips * PER + kGrThreads - 1) / kGrThreads;
 #pragma unroll
         for (int base = 0; base < NIT; base += NB) {
@@ -155,10 +164,11 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv3_group_fwd_kernel(GroupCon
         }
     }
     __syncthreads();                                                            // a2's region becomes the reduction scratch
-    group_stats<kFuC3, kGrWaves / 4>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride);
+    group_stats<kFuC3, kGrWaves / 4>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride, g.acc);
 }
 
-struct GroupConv4Args { const float *z3, *sc3, *sh3; const __bf16 *f4[3]; float *z4; double *partial; int stride, B; };
+// in.acc / acc: as in GroupConv3Args (BatchNorm-3's coefficients from conv3's accumulator set; this kernel's sums to conv4's)
+struct GroupConv4Args { const float *z3, *sc3, *sh3; const __bf16 *f4[3]; float *z4; double *partial; int stride, B; BnAccFwd in; double *acc; };
 
 __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_fwd_kernel(GroupConv4Args g)
 {
@@ -175,12 +185,20 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_fwd_kernel(GroupCon
     // a3 = relu6(BN3(z3)), split once per element, into the planes
     {
         constexpr int PER = kFuH3 * kFuW3 * kFuC3 / 4;                          // float4 per clip: 192
+        static_assert(kGrThreads % 16 == 0, "a thread's channel quad is the same for all of its items");
+        __shared__ __attribute__((aligned(16))) float cf3[2 * kFuC3];
+        f32x4 sc, sh;
+        if (g.in.acc) {
+            bn_fwd_coef_prologue(g.in, kFuC3, cf3, cf3 + kFuC3);
+            sc = *reinterpret_cast<const f32x4 *>(cf3 + 4 * (tid & 15)); sh = *reinterpret_cast<const f32x4 *>(cf3 + kFuC3 + 4 * (tid & 15));
+        } else {
+            sc = *reinterpret_cast<const f32x4 *>(g.sc3 + 4 * (tid & 15)); sh = *reinterpret_cast<const f32x4 *>(g.sh3 + 4 * (tid & 15));
+        }
         for (int i = tid; i < kFuClips * PER; i += kGrThreads) {
             const int c = i / PER, r = i - c * PER, pos = r >> 4, u4 = r & 15;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (b0 + c < g.B) {
                 const f32x4 z = *reinterpret_cast<const f32x4 *>(g.z3 + ((long)(b0 + c) * PER + r) * 4);
-                const f32x4 sc = *reinterpret_cast<const f32x4 *>(g.sc3 + 4 * u4), sh = *reinterpret_cast<const f32x4 *>(g.sh3 + 4 * u4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = relu6f(fmaf(z[e], sc[e], sh[e]));
             }
@@ -233,7 +251,7 @@ __global__ __launch_bounds__(kGrThreads, 1) void conv4_group_fwd_kernel(GroupCon
         }
     }
     __syncthreads();
-    group_stats<kFuC4, kGrWaves / 8>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride);
+    group_stats<kFuC4, kGrWaves / 8>(s, ss, ch, grp, lq, reinterpret_cast<double *>(gr_lds), g.partial, g.stride, g.acc);
 }
 
 // conv4's DATA gradient in the same form: dz4 arrives as the h / m / l bf16 planes BatchNorm-4's backward wrote ((B, 4, 3, 128) each), so

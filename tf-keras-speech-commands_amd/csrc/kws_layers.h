@@ -109,6 +109,38 @@ __global__ void bn_finalize_train_kernel(const double *__restrict__ partial, int
     moving_var[c] = (float)((double)moving_var[c] * kBnMomentum + unbiased * (1.0 - kBnMomentum));
 }
 
+// The accumulator form of the training statistics (kws_device.h: acc_add): the producer's blocks added sum and sum of squares per channel
+// to `acc`; every consumer block derives scale / shift itself (threads < C, into `sc` / `sh`: LDS), with bn_finalize_train_kernel's
+// arithmetic; block 0 also writes the coefficient arrays the backward pass reads and the moving statistics, and clears the set of the
+// other parity.  Contains a barrier.
+struct BnAccFwd { const double *acc; double *acc_clear_set; long M; const float *gamma, *beta; float *moving_mean, *moving_var; BnCoef k; };
+__device__ __forceinline__ void bn_fwd_coef_prologue(const BnAccFwd &a, int C, float *sc, float *sh)
+{
+    const int c = threadIdx.x;
+    if (c < C) {
+        const double s = acc_sum(a.acc, 2 * C, c), ss = acc_sum(a.acc, 2 * C, C + c);
+        const double mean = s / (double)a.M;
+        double var = ss / (double)a.M - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        const double inv = 1.0 / sqrt(var + (double)kBnEps);
+        const double scd = (double)a.gamma[c] * inv;
+        const float scf = (float)scd, shf = (float)((double)a.beta[c] - mean * scd);
+        sc[c] = scf;
+        sh[c] = shf;
+        if (blockIdx.x == 0) {
+            a.k.scale[c] = scf;
+            a.k.shift[c] = shf;
+            a.k.mean[c] = (float)mean;
+            a.k.inv[c] = (float)inv;
+            const double unbiased = var * ((double)a.M / (double)(a.M > 1 ? a.M - 1 : 1));
+            a.moving_mean[c] = (float)((double)a.moving_mean[c] * kBnMomentum + mean * (1.0 - kBnMomentum));
+            a.moving_var[c] = (float)((double)a.moving_var[c] * kBnMomentum + unbiased * (1.0 - kBnMomentum));
+        }
+    }
+    if (blockIdx.x == 0 && a.acc_clear_set) acc_clear(a.acc_clear_set, threadIdx.x, blockDim.x);
+    __syncthreads();
+}
+
 // inference: moving statistics
 __global__ void bn_infer_coef_kernel(int C, const float *__restrict__ gamma, const float *__restrict__ beta,
                                      const float *__restrict__ moving_mean, const float *__restrict__ moving_var, BnCoef k)
@@ -179,6 +211,40 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const float *__restric
     v = relu6f(v);
     if (drop_rate > 0.f) v = dropout_keep(seed_lo, seed_hi, (uint32_t)idx, drop_rate) ? v / (1.f - drop_rate) : 0.f;
     a[idx] = v;
+}
+
+// bn_act_pool_kernel<true> in the accumulator form: every block derives the layer's scale / shift itself (C <= 128), grid-stride
+__global__ __launch_bounds__(256) void bn_act_pool_acc_kernel(const float *__restrict__ z, BnAccFwd in, float *__restrict__ a, int B, int H, int W,
+                                                               int C, float drop_rate, uint32_t seed_lo, uint32_t seed_hi,
+                                                               float *__restrict__ zmax_out, unsigned char *__restrict__ arg_out)
+{
+    __shared__ float cf[256];
+    bn_fwd_coef_prologue(in, C, cf, cf + 128);
+    const int Hp = H / 2, Wp = W / 2;
+    const long total = (long)B * Hp * Wp * C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        long t = idx / C;
+        const int pw = (int)(t % Wp);
+        t /= Wp;
+        const int ph = (int)(t % Hp), b = (int)(t / Hp);
+        const float sc = cf[c], sh = cf[128 + c];
+        const float *p = z + (((long)b * H + 2 * ph) * W + 2 * pw) * C + c;
+        const float z0 = p[0], z1 = p[C], z2 = p[(long)W * C], z3 = p[(long)W * C + C];
+        const float y0 = fmaf(z0, sc, sh), y1 = fmaf(z1, sc, sh), y2 = fmaf(z2, sc, sh), y3 = fmaf(z3, sc, sh);
+        float v = fmaxf(fmaxf(y0, y1), fmaxf(y2, y3));
+        int arg = 0;                         // first maximum of relu6(y): the element the backward pass routes the gradient to
+        float best = relu6f(y0), zm = z0;
+        const float v1 = relu6f(y1), v2 = relu6f(y2), v3 = relu6f(y3);
+        if (v1 > best) { best = v1; arg = 1; zm = z1; }
+        if (v2 > best) { best = v2; arg = 2; zm = z2; }
+        if (v3 > best) { arg = 3; zm = z3; }
+        zmax_out[idx] = zm;
+        arg_out[idx] = (unsigned char)arg;
+        v = relu6f(v);
+        if (drop_rate > 0.f) v = dropout_keep(seed_lo, seed_hi, (uint32_t)idx, drop_rate) ? v / (1.f - drop_rate) : 0.f;
+        a[idx] = v;
+    }
 }
 
 // backward through dropout / max-pool / ReLU6 to the BN output: writes g = dL/dy per z element and the per-channel

@@ -386,11 +386,13 @@ static int split_weights(const kws_model *m, const float *params, CnnWs &w, hipS
     KWS_LAUNCH("weight_split_kernel", weight_split_kernel, dim3(64, 3), dim3(256), 0, s, all);
     return KWS_OK;
 }
-static int launch_group_conv3(const kws_model *m, int B, CnnWs &w, hipStream_t s, bool fuse_pool2)
+static int launch_group_conv3(const kws_model *m, int B, CnnWs &w, hipStream_t s, bool fuse_pool2, const BnAccFwd *in2 = nullptr, double *acc3 = nullptr)
 {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv3_group_fwd_kernel), 4 * kFuA2)) return rc;
     GroupConv3Args a{};
     a.a2 = w.a[1]; a.z3 = w.z[2]; a.partial = w.partial; a.stride = kStatStride; a.B = B;
+    if (in2) a.in = *in2;               // BatchNorm-2's coefficients from conv2's accumulator set
+    a.acc = acc3;
     if (fuse_pool2) {            // layer 2's BatchNorm -> ReLU6 -> max-pool happens while the tile is staged (bn_act_pool_kernel<true>'s contract)
         const BnCoef k2 = coef_of(w.coef[1], 32);
         a.z2 = w.z[1]; a.sc2 = k2.scale; a.sh2 = k2.shift; a.a2w = w.a[1]; a.zmax2 = w.zmax2; a.arg2 = w.arg2;
@@ -419,10 +421,12 @@ static int launch_group_dgrad4(const kws_model *m, int B, CnnWs &w, hipStream_t 
     KWS_LAUNCH("conv_group_dgrad<128,64>", conv4_group_dgrad_kernel, dim3(blocks_for(B, kFuClips)), dim3(kGrThreads), (size_t)(6 * kGrD4P), s, a);
     return (int)blocks_for(B, kFuClips);
 }
-static int launch_group_conv4(const kws_model *m, int B, CnnWs &w, hipStream_t s)
+static int launch_group_conv4(const kws_model *m, int B, CnnWs &w, hipStream_t s, const BnAccFwd *in3 = nullptr, double *acc4 = nullptr)
 {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv4_group_fwd_kernel), 6 * kFuA3P)) return rc;
     GroupConv4Args a{};
+    if (in3) a.in = *in3;
+    a.acc = acc4;
     const BnCoef k3 = coef_of(w.coef[2], 64);
     a.z3 = w.z[2]; a.sc3 = k3.scale; a.sh3 = k3.shift; a.z4 = w.z[3]; a.partial = w.partial; a.stride = kStatStride; a.B = B;
     for (int p = 0; p < 3; ++p) a.f4[p] = w.wsp[1][3 + p];
@@ -588,6 +592,21 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool a3_on_load = cnn_a3_on_load(m, bf16, training);
     const bool routed_bwd2 = cnn_compact_g2(m, bf16);
     const bool fuse_pool2 = group_fwd && routed_bwd2 && d.H1 == kGrH1 && d.W1 == kGrW1;
+    // finalize-free batch statistics (kws_device.h: acc_add), non-deterministic training at the default geometry: conv2 .. conv4 add their
+    // sums to accumulator sets and the next kernel of the chain derives scale / shift in its prologue -- three launches less
+    const bool acc_fwd = fuse_pool2 && !m->deterministic && kCh[4] <= 128;
+    unsigned fpar = 0;
+    if (acc_fwd) {
+        if (!R) R = const_cast<kws_model *>(m)->dev_res();
+        if (!R) return fail(KWS_ERR_HIP, "cannot create the model's side stream / events on this device");
+        fpar = R->fwd_passes++;
+        KWS_TRY(acc_make_clean(R, s));
+        R->acc_dirty = true;               // until every kernel of this pass is enqueued
+    }
+    auto acc_in = [&](int l) {             // the consumer's view of layer l's statistics
+        return BnAccFwd{acc_set(R, 0, l, fpar), acc_set(R, 0, l, fpar + 1), (long)B * Hz[l] * Wz[l], params + m->o_g[l], params + m->o_b[l],
+                        state + m->o_mm[l], state + m->o_mv[l], coef_of(w.coef[l], kCh[l + 1])};
+    };
     for (int l = 1; l < 4; ++l) {
         const float *in = w.a[l - 1];
         const float *kern = params + m->o_k[l];
@@ -601,7 +620,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             const size_t smb = std::max((size_t)6 * 16 * (((Hs[1] + 2) * (Ws[1] + 2) + 15) & ~15), sizeof(double) * 4 * 2 * 16);
             if (training && bf16) {
                 KWS_LAUNCH("conv_fwd_clip_bf16<16,32>", (conv_fwd_clip_bf16_kernel<true>), dim3(nblk), dim3(256), smb, s, in, kern, w.z[1], B, Hs[1],
-                           Ws[1], w.partial, kStatStride);
+                           Ws[1], w.partial, kStatStride, nullptr, nullptr, acc_fwd ? acc_set(R, 0, 1, fpar) : nullptr);
                 fused_stat_blocks = (int)nblk;
             } else if (training) {
                 KWS_LAUNCH("conv_fwd_clip<16,32>", (conv_fwd_clip_kernel<32, true>), dim3(nblk), dim3(256), sm, s, in, kern, w.z[1], B, Hs[1], Ws[1],
@@ -634,7 +653,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             if (bf16 && training && !prep_in_stats) KWS_HIP_CHECK(hipStreamWaitEvent(s, R->ev[11], 0));     // the weight planes are ready
             // the split-precision kernels write the BatchNorm partial sums from their epilogue when training
             if (group_fwd) {
-                fused_stat_blocks = launch_group_conv3(m, B, w, s, fuse_pool2);
+                if (acc_fwd) { const BnAccFwd in2 = acc_in(1); fused_stat_blocks = launch_group_conv3(m, B, w, s, fuse_pool2, &in2, acc_set(R, 0, 2, fpar)); }
+                else fused_stat_blocks = launch_group_conv3(m, B, w, s, fuse_pool2);
                 if (fused_stat_blocks < 0) return fused_stat_blocks;
             } else if (bf16) {
                 fused_stat_blocks = launch_bf16<32, 64, MODE_FWD, EPI_NONE>("conv_bf16_fwd", in, w.wsp[0], nullptr, w.z[2], geom3x3(B, Hs[2], Ws[2], 2), s,
@@ -644,7 +664,9 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         } else {
             // activation='relu', cnn.py:55
             if (group_fwd) {
-                fused_stat_blocks = launch_group_conv4(m, B, w, s);          // forms a3 = relu6(BN3(z3)) while staging, like the ABN form below
+                // forms a3 = relu6(BN3(z3)) while staging, like the ABN form below
+                if (acc_fwd) { const BnAccFwd in3 = acc_in(2); fused_stat_blocks = launch_group_conv4(m, B, w, s, &in3, acc_set(R, 0, 3, fpar)); }
+                else fused_stat_blocks = launch_group_conv4(m, B, w, s);
                 if (fused_stat_blocks < 0) return fused_stat_blocks;
             } else if (bf16) {
                 // training: a3 = relu6(BN3(z3)) is never written -- conv4 forms it from z3 while it stages its rows, and so does conv4's
@@ -657,7 +679,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         }
         if (hook && l < 3) KWS_TRY(hook->fire(8 + l, s));     // 9 behind conv2's forward, 10 behind conv3's
         BnCoef k = coef_of(w.coef[l], C);
-        if (training) {
+        if (training && acc_fwd) ;          // the next kernel of the chain derives the coefficients from the accumulator set
+        else if (training) {
             int nblk, rows;
             stat_grid(M, C, nblk, rows);
             if (fused_stat_blocks) nblk = fused_stat_blocks;
@@ -681,6 +704,10 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             unsigned char *ag = nullptr;
             if (l == 1 && training && routed_bwd2) { zm = w.zmax2; ag = w.arg2; }
             if (l == 3 && training && bf16) { zm = w.zmax4; ag = w.arg4; }
+            if (l == 3 && acc_fwd)
+                KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_acc_kernel, dim3(std::min<unsigned>(1024u, blocks_for(total, 256))), dim3(256), 0, s,
+                           w.z[l], acc_in(3), w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi, zm, ag);
+            else
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
                                w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi, zm, ag);
         } else if (!(l == 2 && a3_on_load)) {
@@ -699,6 +726,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     else KWS_TRY(launch_gemm<128, 128, MODE_FWD, EPI_BIAS_RELU6>(w.a[3], params + m->o_dk, params + m->o_db, w.d1, g, s));
     if (hook) KWS_TRY(hook->fire(7, s));
     KWS_LAUNCH_CHECK("simple_cnn forward");
+    if (acc_fwd) R->acc_dirty = false;
     return KWS_OK;
 }
 

@@ -219,8 +219,8 @@ typedef struct kws_train_args {
                                    featurization) can be ordered after it                                       */
     void *overlap_event;        /* NULL or a hipEvent_t recorded on `stream` at the best point of the step to start independent
                                    vector-ALU / memory work on another stream (the next batch's featurization).  simple_cnn: behind
-                                   the last BatchNormalization's activation kernel, in front of the dense layer (sweeps of eight points
-                                   at B = 4096 on four boxes: 0.681-0.691 ms per step there, 0.729 at forward_event; kws_model.hip);
+                                   conv3's forward kernel (round 3's sweep of eleven points at B = 4096: 0.548 ms per step there,
+                                   0.579 at forward_event; kws_model.hip; kws_model_set_overlap_point moves it);
                                    simple_cnn_lite and the recurrent models record it together with forward_event.          */
     void (*overlap_callback)(void *user);   /* NULL or a host function the call invokes (same thread, once) right after it has
                                    enqueued the work overlap_event marks: enqueueing the next batch's kws_featurize from it
@@ -286,7 +286,7 @@ int kws_model_get_precision(const kws_model *m, int *matrix, int *infer);
 int kws_model_set_deterministic(kws_model *m, int on);
 
 /* Tuning aid: where in the simple_cnn train step kws_train_args.overlap_event is recorded / overlap_callback is called.  -1 (default):
- * the library's choice (6 = behind the last BatchNormalization's activation kernel); 0 behind the last forward convolution, 1 behind
+ * the library's choice (10 = behind conv3's forward); 6 behind the last BatchNormalization's activation kernel, 0 behind the last forward convolution, 1 behind
  * the loss, 2 behind the head's backward kernel, 3 behind the dense data gradient, 4 behind BatchNorm-4's backward, 5 behind conv4's
  * data gradient, 7 behind the dense forward product, 8 behind layer 1's forward kernel, 9 behind conv2's forward, 10 behind conv3's.
  * Changes scheduling only, never results (tests/test_model_gpu.py). */

@@ -664,7 +664,7 @@ def test_overlap_point_changes_scheduling_only(torch):
 
 @pytest.mark.parametrize("model_type", ["simple_cnn", "simple_cnn_lite", "simple_gru"])
 def test_overlap_and_forward_events_are_recorded_in_order(torch, model_type):
-    """kws_train_args.overlap_event (simple_cnn: behind the last BatchNormalization's activation, in front of the dense layer) and
+    """kws_train_args.overlap_event (simple_cnn: behind conv3's forward kernel by default) and
     forward_event (behind the loss) are recorded on the caller's stream by every model kind, overlap first; a side stream ordered
     behind overlap_event may overwrite the NEXT batch's feature buffer while the step runs, and the step's results do not depend on
     the events being requested."""

@@ -1607,7 +1607,11 @@ int kws_model_train_fwd_bwd(kws_model *m, const kws_train_args *a, void *stream)
     // BatchNorm-4's backward 0.721, behind conv4's data gradient 0.699.  Behind the head's backward kernel (point 2) was the best point on two
     // boxes (0.686) and the worst on two others (0.709-0.722, whatever the hardware-queue count): the featurizer then starts together with
     // the side stream's weight-gradient chain, and which of the two gets the chip first decides.  kws_model_set_overlap_point(m, 0 .. 7) re-runs the sweep.
-    hook.at = lite ? 1 : (m->overlap_point >= 0 ? m->overlap_point : 6);     // kws_model_set_overlap_point re-runs the sweep
+    // Round 3, after the finalize-free BatchNorm chain (fewer, shorter kernels behind conv4): behind conv3's forward (point 10) 0.548, behind
+    // conv4's forward 0.552, behind BN4's backward 0.556, point 6 0.561, behind layer 1 0.575, behind the loss 0.579 (two rounds, one box):
+    // the featurizer's persistent blocks (62 KB of LDS per CU) then run beside conv4's forward, the activation and the Dense + head kernel,
+    // which fit beside them, and are gone when conv4's data gradient needs 147 KB of every CU.
+    hook.at = lite ? 1 : (m->overlap_point >= 0 ? m->overlap_point : 10);     // kws_model_set_overlap_point re-runs the sweep
     rc = lite ? lite_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s)
               : cnn_forward(m, a->feat, a->B, a->params, a->state, w, true, a->dropout_seed, s, a->grads, &grads_zeroed, &hook, a->feat_moments);
     if (rc) return rc;

@@ -46,7 +46,7 @@ class FeaturePipeline(object):
         featurized here, or `features` (rows, n_features, feature_size); `index` (CUDA int32) picks the batch's rows from either
         (default: every row); `labels` (rows,) int32 are gathered with the same index.  `after`: an event on the main stream to
         start behind -- best the running step's overlap_event (DeviceModel.train_fwd_bwd(overlap_event=...), recorded at the point
-        of the step that a sweep found best for this -- for simple_cnn behind the last BatchNormalization's activation kernel,
+        of the step that a sweep found best for this -- for simple_cnn behind conv3's forward kernel (round 3's sweep),
         include/kws.h); call submit from train_fwd_bwd's overlap_callback so that the launch also sits there in host order;
         default: everything enqueued so far."""
         torch = _torch()

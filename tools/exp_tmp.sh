@@ -1,2 +1,8 @@
-python -m pytest tests/test_model_gpu.py tests/test_dp_rccl_gpu.py tests/test_host_api_gpu.py -x -q 2>&1 | tail -5
-python tools/ab_libs.py 2 - tools/lib_prev.bin 2>&1 | cut -c1-60
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+python bench.py 2>/dev/null | tail -1 > gpurun_out/r3_bench_v3.json
+python bench.py --steps 20 --warmup 5 --no-extra 2>/dev/null | tail -1 > gpurun_out/r3_bench_v3_driver.json
+python -c "
+import json
+for f in ('gpurun_out/r3_bench_v3.json','gpurun_out/r3_bench_v3_driver.json'):
+    d=json.load(open(f)); print(f, d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('extra',{}).get('fit_api_step',{}))
+"

@@ -220,11 +220,7 @@ int launch_wgrad_bf16(const float *x, const float *dz, float *dw, const ConvGeom
     constexpr size_t stage = (size_t)3 * 32 * 4 * (TPB * tr_row_words(CIN) + tr_row_words(COUT)), tile = (size_t)CIN * COUT * sizeof(float);
     constexpr size_t smem = stage > tile ? stage : tile;
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>), (int)smem)) return rc;
-    static const int occ0 = resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>, 256, smem);
-    int occ = occ0;
-#ifdef KWS_EXP
-    { const char *e = getenv(CIN == 64 ? "KWS_X_OCCW4" : "KWS_X_OCCW3"); if (e) occ = std::min(occ0, atoi(e)); }
-#endif
+    static const int occ = resident_blocks(conv_wgrad_bf16_kernel<CIN, COUT, TPB, DPRE, XBN>, 256, smem);
     const long M = (long)g.B * g.Ho * g.Wo, nchunk = (M + 31) / 32;
     const int ngroups = g.KH * g.KW / TPB;
     // ranges: a multiple of 8 (one per XCD), at most one resident round, at least 4 chunks per block
@@ -976,11 +972,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             const size_t smwb = std::max((size_t)3 * 32 * (H1 + 2) * (W1 + 2) + (size_t)6 * 32 * (H1 * W1 + 1), sizeof(float) * 9 * 16 * 32);
             // two blocks per CU although three fit: the third takes the LDS the layer-1 kernels of the main chain need beside it
             // (same-box A/B: 0.785 ms/step with one or two, 0.800 with three); deterministic: one persistent block walks every clip
-            int wg2_cap = 2, dg2_cap = 2;
-#ifdef KWS_EXP
-            { const char *e = getenv("KWS_X_OCCW2"); if (e) wg2_cap = atoi(e); e = getenv("KWS_X_OCCD2"); if (e) dg2_cap = atoi(e); }
-#endif
-            auto wgrad_grid = [&](int occ) { return dim3(det ? 1u : even_grid(cu_count() * std::min(occ, wg2_cap))); };
+            auto wgrad_grid = [&](int occ) { return dim3(det ? 1u : even_grid(cu_count() * std::min(occ, 2))); };
             if (wgrad_early) {
                 if (int rc = fork(1)) return rc;
                 static const int occ = resident_blocks(conv_wgrad_clip_bf16_kernel<true>, 256, smwb);
@@ -991,7 +983,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
                 // split-precision form: 2 blocks per CU by registers (the weight fragments of all nine taps stay in them)
                 const size_t smdb = (size_t)12 * 16 * (((H1 + 2) * (W1 + 2) + 15) & ~15);
                 if (wgrad_early)
-                    KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true, false>), dim3(even_grid(cu_count() * dg2_cap)), dim3(256), smdb, s,
+                    KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true, false>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s,
                                w.gz[1], kern, w.da[0], B, H1, W1, bn);
                 else if (compact_g)
                     KWS_LAUNCH("conv_dgrad_clip_bf16<32,16>", (conv_dgrad_clip_bf16_kernel<true, true>), dim3(even_grid(cu_count() * 2)), dim3(256), smdb, s,

@@ -1000,6 +1000,16 @@ def test_feature_moments_match_numpy_and_feed_the_step(torch):
     assert q[9, 9] == B * 600
     q2 = mom(xt).cpu().numpy().reshape(10, 10)
     np.testing.assert_array_equal(q, q2)                      # fixed summation order
+    # another even map (width not a multiple of four, pixels not a multiple of 64) and a batch with a ragged last block
+    rng = np.random.default_rng(93)
+    for (Bx, H, W) in ((203, 24, 14), (5000, 8, 6)):
+        xg = rng.standard_normal((Bx, H, W)).astype(np.float32)
+        qg = FeatureMoments(H, W)(torch.from_numpy(xg).cuda()).cpu().numpy().reshape(10, 10)
+        xq = np.zeros((Bx, H + 2, W + 2))
+        xq[:, 1:H + 1, 1:W + 1] = xg
+        ag = np.stack([xq[:, kh:kh + H, kw:kw + W] for kh in range(3) for kw in range(3)] + [np.ones((Bx, H, W))], -1).reshape(-1, 10)
+        np.testing.assert_allclose(qg, ag.T @ ag, rtol=2e-6, atol=2e-3)
+        assert qg[9, 9] == Bx * H * W
     y = torch.from_numpy(np.random.default_rng(92).integers(0, C, B).astype(np.int32)).cuda()
     res = []
     for supplied in (False, True):

@@ -30,6 +30,14 @@ struct DenseHeadArgs {
     double *acc4 = nullptr;
     float drop_rate = 0.f;
     uint32_t seed_lo = 0, seed_hi = 0;
+    // z4 != nullptr: the kernel is ALSO layer 4's activation pass (bn_act_pool_acc_kernel's contract, kws_layers.h): BatchNorm-4's scale /
+    // shift come from the accumulator set conv4's forward added to (in4), a4 = dropout(maxpool(relu6(BN4(z4)))) is formed from z4 (B, H3, W3,
+    // 128) while the tile is staged and written to a4w (the Dense weight gradient reads it) with zmax4w / arg4w for the backward pass
+    const float *z4 = nullptr;
+    BnAccFwd in4{};
+    float *a4w = nullptr, *zmax4w = nullptr;
+    unsigned char *arg4w = nullptr;
+    int H3 = 0, W3 = 0;
 };
 
 __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
@@ -50,6 +58,57 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
     fu_load_b(g.fd, 2 * wave, lane, bcur[0]);
     fu_load_b(g.fd, 2 * wave + 1, lane, bcur[1]);
     for (int i = tid; i < K * kDhCP; i += 256) { const int k = i / kDhCP, c = i - k * kDhCP; ws[k * kDhCS + c] = c < C ? g.w2[(long)k * C + c] : 0.f; }
+    __shared__ __attribute__((aligned(16))) float cf4[4 * kDhK];   // z4: BatchNorm-4's scale | shift | mean | inv, derived here
+    if (g.z4) {
+        bn_fwd_coef_prologue(g.in4, kDhK, cf4, cf4 + kDhK, cf4 + 2 * kDhK, cf4 + 3 * kDhK);
+        const int W4 = g.W3 / 2, nf4 = g.flat / 4;                // pooled width; float4 units per clip
+        constexpr int NB = 2;                                     // items per thread in flight: their eight window loads precede the first store
+        for (int base = tid; base < 16 * nf4; base += NB * 256) {
+            f32x4 z[NB][4];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int i = base + 256 * k, r = i / nf4, u = i - r * nf4, win = u / (kDhK / 4), c0 = 4 * (u - win * (kDhK / 4));
+                const int ph = win / W4, pw = win - ph * W4;
+                const bool ok = i < 16 * nf4 && b0 + r < g.B;
+                const float *zp = g.z4 + ((((long)(b0 + r) * g.H3 + 2 * ph) * g.W3 + 2 * pw) * kDhK + c0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    z[k][j] = ok ? *reinterpret_cast<const f32x4 *>(zp + ((j >> 1) * g.W3 + (j & 1)) * kDhK) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int i = base + 256 * k, r = i / nf4, u = i - r * nf4, c0 = 4 * (u % (kDhK / 4));
+                if (i >= 16 * nf4) continue;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (b0 + r < g.B) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4 *>(cf4 + c0), sh = *reinterpret_cast<const f32x4 *>(cf4 + kDhK + c0);
+                    const long o = (long)(b0 + r) * g.flat + 4 * u;
+                    f32x4 zm;
+                    unsigned am = 0u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y0 = fmaf(z[k][0][e], sc[e], sh[e]), y1 = fmaf(z[k][1][e], sc[e], sh[e]);
+                        const float y2 = fmaf(z[k][2][e], sc[e], sh[e]), y3 = fmaf(z[k][3][e], sc[e], sh[e]);
+                        float a = relu6f(fmaxf(fmaxf(y0, y1), fmaxf(y2, y3)));
+                        unsigned arg = 0u;                   // first maximum of relu6(y): the element the backward pass routes the gradient to
+                        float best = relu6f(y0), zz = z[k][0][e];
+                        const float v1 = relu6f(y1), v2 = relu6f(y2), v3 = relu6f(y3);
+                        if (v1 > best) { best = v1; arg = 1u; zz = z[k][1][e]; }
+                        if (v2 > best) { best = v2; arg = 2u; zz = z[k][2][e]; }
+                        if (v3 > best) { arg = 3u; zz = z[k][3][e]; }
+                        zm[e] = zz;
+                        am |= arg << (8 * e);
+                        if (g.drop_rate > 0.f) a = dropout_keep(g.seed_lo, g.seed_hi, (uint32_t)(o + e), g.drop_rate) ? a / (1.f - g.drop_rate) : 0.f;
+                        v[e] = a;
+                    }
+                    *reinterpret_cast<f32x4 *>(g.a4w + o) = v;
+                    *reinterpret_cast<f32x4 *>(g.zmax4w + o) = zm;
+                    *reinterpret_cast<unsigned *>(g.arg4w + o) = am;
+                }
+                *reinterpret_cast<f32x4 *>(a4s + r * RS4 + 4 * u) = v;
+            }
+        }
+    } else
     for (int i = tid; i < 16 * (g.flat / 4); i += 256) {
         const int r = i / (g.flat / 4), u = i - r * (g.flat / 4);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -205,7 +264,9 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
             if (g.acc4) {
                 // flat index = (pool window) * 128 + channel: dropout mask, ReLU6 gate on y = BN4(z of the routed element), sums
                 const int ch = 16 * ctl + li;
-                const float gsc = g.coef4[ch], gsh = g.coef4[kDhK + ch], gmean = g.coef4[2 * kDhK + ch], ginv = g.coef4[3 * kDhK + ch];
+                // (with z4 the global coefficient arrays are being written by block 0 of THIS launch: every block uses its own copy)
+                const float *cf = g.z4 ? cf4 : g.coef4;
+                const float gsc = cf[ch], gsh = cf[kDhK + ch], gmean = cf[2 * kDhK + ch], ginv = cf[3 * kDhK + ch];
                 float s = 0.f, sx = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)

@@ -114,7 +114,7 @@ __global__ void bn_finalize_train_kernel(const double *__restrict__ partial, int
 // arithmetic; block 0 also writes the coefficient arrays the backward pass reads and the moving statistics, and clears the set of the
 // other parity.  Contains a barrier.
 struct BnAccFwd { const double *acc; double *acc_clear_set; long M; const float *gamma, *beta; float *moving_mean, *moving_var; BnCoef k; };
-__device__ __forceinline__ void bn_fwd_coef_prologue(const BnAccFwd &a, int C, float *sc, float *sh)
+__device__ __forceinline__ void bn_fwd_coef_prologue(const BnAccFwd &a, int C, float *sc, float *sh, float *mean_out = nullptr, float *inv_out = nullptr)
 {
     const int c = threadIdx.x;
     if (c < C) {
@@ -127,6 +127,7 @@ __device__ __forceinline__ void bn_fwd_coef_prologue(const BnAccFwd &a, int C, f
         const float scf = (float)scd, shf = (float)((double)a.beta[c] - mean * scd);
         sc[c] = scf;
         sh[c] = shf;
+        if (mean_out) { mean_out[c] = (float)mean; inv_out[c] = (float)inv; }      // a kernel that also runs the layer's backward reduction
         if (blockIdx.x == 0) {
             a.k.scale[c] = scf;
             a.k.shift[c] = shf;

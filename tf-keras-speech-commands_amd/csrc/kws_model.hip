@@ -690,9 +690,12 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
         if (l == 3 && hook) KWS_TRY(hook->fire(0, s));
         // overlap point 6 sits right behind this layer's activation kernel: the caller's event rides on that kernel's completion signal
         // instead of a marker packet of its own (kws_common.h: ArmedEvent)
-        const bool arm6 = l == 3 && hook && hook->wants(6) && hook->ev;
+        // layer 4's activation rides in the fused Dense + head kernel of the backward pass (kws_dense_head.h: z4): no kernel here
+        const bool pool4_fused = l == 3 && acc_fwd && dense_fused;
+        const bool arm6 = l == 3 && hook && hook->wants(6) && hook->ev && !pool4_fused;
         if (arm6) arm_stop_event(hook->ev, s);
-        if (l == 1 && fuse_pool2) ;                    // conv3's group kernel forms a2 (and zmax2 / arg2) from z2 while it stages its tile
+        if (pool4_fused) { R->pool4_pending = true; R->pool4_mm = state + m->o_mm[3]; R->pool4_mv = state + m->o_mv[3]; }
+        else if (l == 1 && fuse_pool2) ;               // conv3's group kernel forms a2 (and zmax2 / arg2) from z2 while it stages its tile
         else if (pool[l]) {
             const long total = (long)B * (Hz[l] / 2) * (Wz[l] / 2) * C;
             // training: the routed element of every window for the backward reduction (layer 2: compact g; layer 4: full-size g)
@@ -792,6 +795,14 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (acc_bn4) {
                 da.zmax4 = w.zmax4; da.coef4 = coef_of(w.coef[3], 128).scale; da.acc4 = acc_set(R, 1, 3, par);
                 da.drop_rate = seed != 0 ? 0.5f : 0.f; da.seed_lo = slo; da.seed_hi = shi;
+            }
+            if (R->pool4_pending) {             // the forward pass of this step left layer 4's activation to this kernel
+                const unsigned fpar = R->fwd_passes - 1;
+                da.z4 = w.z[3]; da.a4w = w.a[3]; da.zmax4w = w.zmax4; da.arg4w = w.arg4; da.H3 = Hz[3]; da.W3 = Wz[3];
+                da.in4 = BnAccFwd{acc_set(R, 0, 3, fpar), acc_set(R, 0, 3, fpar + 1), (long)B * Hz[3] * Wz[3], params + m->o_g[3], params + m->o_b[3],
+                                  R->pool4_mm, R->pool4_mv, coef_of(w.coef[3], 128)};
+                da.drop_rate = seed != 0 ? 0.5f : 0.f; da.seed_lo = slo; da.seed_hi = shi;
+                R->pool4_pending = false;
             }
             da.fw = HeadFwdArgs{params + m->o_hb, a->labels, a->class_weights, a->probs, w.loss_i, w.correct_i, a->grad_scale / (float)B, a->ignore_index};
             const size_t smem = sizeof(float) * (size_t)(16 * (d.flat + 8) + 2 * 16 * kDhKS + 16 * kDhCS + kDhK * kDhCS);

@@ -28,6 +28,8 @@ struct ModelRes {
     double *acc = nullptr;
     unsigned fwd_passes = 0, bwd_passes = 0;
     bool acc_dirty = false;             // an enqueue failed half-way: clear everything before the next pass
+    bool pool4_pending = false;         // the forward pass left layer 4's activation to the fused Dense + head kernel of the backward pass
+    float *pool4_mm = nullptr, *pool4_mv = nullptr;     // ... and these are BatchNorm-4's moving statistics it will update
 };
 
 struct CnnDims { int H0, W0, H1, W1, H2, W2, H3, W3, H4, W4, flat; };

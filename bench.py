@@ -49,7 +49,8 @@ PMC_SOURCES = {"feat": ("kws_featurize.hip", "kws_featurize_v3.h"), "feat_shared
                "gru": ("kws_rnn.hip", "kws_gru.h"), "lstm": ("kws_rnn.hip", "kws_lstm.h"),
                "lite16": ("kws_lite.h", "kws_lite_f16.h", "kws_featurize.hip", "kws_featurize_v3.h"),
                "infer": ("kws_model.hip", "kws_conv.h", "kws_layers.h", "kws_layer1.h", "kws_infer_fused.h", "kws_featurize.hip", "kws_featurize_v3.h"),
-               "step": ("kws_model.hip", "kws_conv.h", "kws_layers.h", "kws_layer1.h", "kws_layer1_fast.h", "kws_layer1_moments.h")}
+               "step": ("kws_model.hip", "kws_conv.h", "kws_conv_group.h", "kws_dense_head.h", "kws_layers.h", "kws_layer1.h", "kws_layer1_fast.h",
+                        "kws_layer1_moments.h", "kws_device.h")}
 _pmc_cache = {}
 
 

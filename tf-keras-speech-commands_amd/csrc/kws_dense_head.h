@@ -40,8 +40,15 @@ struct DenseHeadArgs {
     int H3 = 0, W3 = 0;
 };
 
-__global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
+// kDhWaves waves per block of 16 samples: every phase below is a chain of dependent LDS / L2 round trips with little work per wave, and
+// the kernel shares its CU with the next batch's featurizer (twelve vector-ALU-bound waves) -- eight waves halve the serial work of a
+// wave in the Dense product, the data gradient and the dW2 tiles against four (four waves: 0.037 ms alone, 0.115 under the featurizer).
+constexpr int kDhWaves = 8, kDhThreads = 64 * kDhWaves;
+__global__ __launch_bounds__(kDhThreads) void dense_head_fused_kernel(DenseHeadArgs g)
 {
+    constexpr int NW = kDhWaves, NT = kDhThreads;
+    static_assert(NW == 4 || NW == 8, "column tiles per wave below: 8 / NW Dense tiles, 24 / NW dW2 tiles");
+    constexpr int DT = 8 / NW, WT = 24 / NW;                      // Dense column tiles, dW2 tiles per wave
     extern __shared__ __attribute__((aligned(16))) float dh_lds[];
     const int RS4 = g.flat + 8;                                   // row stride of the a4 tile: 16 B x (2 mod 4) for flat = 256 (multiple of 32)
     float *a4s = dh_lds;                                          // [16][RS4]
@@ -54,20 +61,20 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
     const int nks = g.flat / 32;
 
     // the first Dense weight fragments travel while the tiles are staged
-    bf16x8 bcur[2][3], bnext[2][3];
-    fu_load_b(g.fd, 2 * wave, lane, bcur[0]);
-    fu_load_b(g.fd, 2 * wave + 1, lane, bcur[1]);
-    for (int i = tid; i < K * kDhCP; i += 256) { const int k = i / kDhCP, c = i - k * kDhCP; ws[k * kDhCS + c] = c < C ? g.w2[(long)k * C + c] : 0.f; }
+    bf16x8 bcur[DT][3], bnext[DT][3];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) fu_load_b(g.fd, DT * wave + t, lane, bcur[t]);
+    for (int i = tid; i < K * kDhCP; i += NT) { const int k = i / kDhCP, c = i - k * kDhCP; ws[k * kDhCS + c] = c < C ? g.w2[(long)k * C + c] : 0.f; }
     __shared__ __attribute__((aligned(16))) float cf4[4 * kDhK];   // z4: BatchNorm-4's scale | shift | mean | inv, derived here
     if (g.z4) {
         bn_fwd_coef_prologue(g.in4, kDhK, cf4, cf4 + kDhK, cf4 + 2 * kDhK, cf4 + 3 * kDhK);
         const int W4 = g.W3 / 2, nf4 = g.flat / 4;                // pooled width; float4 units per clip
         constexpr int NB = 2;                                     // items per thread in flight: their eight window loads precede the first store
-        for (int base = tid; base < 16 * nf4; base += NB * 256) {
+        for (int base = tid; base < 16 * nf4; base += NB * NT) {
             f32x4 z[NB][4];
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const int i = base + 256 * k, r = i / nf4, u = i - r * nf4, win = u / (kDhK / 4), c0 = 4 * (u - win * (kDhK / 4));
+                const int i = base + NT * k, r = i / nf4, u = i - r * nf4, win = u / (kDhK / 4), c0 = 4 * (u - win * (kDhK / 4));
                 const int ph = win / W4, pw = win - ph * W4;
                 const bool ok = i < 16 * nf4 && b0 + r < g.B;
                 const float *zp = g.z4 + ((((long)(b0 + r) * g.H3 + 2 * ph) * g.W3 + 2 * pw) * kDhK + c0);
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
             }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const int i = base + 256 * k, r = i / nf4, u = i - r * nf4, c0 = 4 * (u % (kDhK / 4));
+                const int i = base + NT * k, r = i / nf4, u = i - r * nf4, c0 = 4 * (u % (kDhK / 4));
                 if (i >= 16 * nf4) continue;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (b0 + r < g.B) {
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
             }
         }
     } else
-    for (int i = tid; i < 16 * (g.flat / 4); i += 256) {
+    for (int i = tid; i < 16 * (g.flat / 4); i += NT) {
         const int r = i / (g.flat / 4), u = i - r * (g.flat / 4);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (b0 + r < g.B) v = *reinterpret_cast<const f32x4 *>(g.a4 + (long)(b0 + r) * g.flat + 4 * u);
@@ -117,26 +124,27 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
     }
     __syncthreads();
 
-    // ---- Dense(128) + ReLU6: wave = column tiles 2 wave, 2 wave + 1 ----
+    // ---- Dense(128) + ReLU6: wave = column tiles DT wave .. DT wave + DT - 1 ----
     {
-        f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        f32x4 acc[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int ks = 0; ks < nks; ++ks) {
-            if (ks + 1 < nks) {
-                fu_load_b(g.fd, (long)(ks + 1) * 8 + 2 * wave, lane, bnext[0]);
-                fu_load_b(g.fd, (long)(ks + 1) * 8 + 2 * wave + 1, lane, bnext[1]);
-            }
+            if (ks + 1 < nks)
+#pragma unroll
+                for (int t = 0; t < DT; ++t) fu_load_b(g.fd, (long)(ks + 1) * 8 + DT * wave + t, lane, bnext[t]);
             bf16x8 a[3];
             fu_load_a(a4s + li * RS4 + 32 * ks + 4 * lq, a);
-            acc[0] = mfma_bf16x6(a, bcur[0], acc[0]);
-            acc[1] = mfma_bf16x6(a, bcur[1], acc[1]);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < DT; ++t) acc[t] = mfma_bf16x6(a, bcur[t], acc[t]);
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bcur[t][p] = bnext[t][p];
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int ch = 16 * (2 * wave + t) + li;
+        for (int t = 0; t < DT; ++t) {
+            const int ch = 16 * (DT * wave + t) + li;
             const float bias = g.db[ch];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -147,13 +155,14 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
         }
     }
     // the data gradient's first fragments: column tiles wave, wave + 4, ... of the flat map
-    const int nct = g.flat / 16, tpw = nct / 4;                   // column tiles of da4, per wave
+    const int nct = g.flat / 16, tpw = nct / NW;                  // column tiles of da4, per wave
     __syncthreads();
 
     // ---- head forward: thread (sample sm = tid / 16, lane j = tid % 16) owns classes j, j + 16, j + 32 of its sample (kws_layers.h) ----
     const HeadFwdArgs &fw = g.fw;
     {
-        const int sm = tid >> 4, j = tid & 15, b = b0 + sm;
+        const int sm = (tid >> 4) & 15, j = tid & 15, b = b0 + sm;            // waves 4 .. NW - 1 have no sample: they only meet the barriers
+        const bool has = tid < 256;
         float *lg = ds + sm * kDhCS;
         if (wave < kDhCP / 16) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
             for (int r = 0; r < 4; ++r) ds[(4 * lq + r) * kDhCS + cc] = acc[r] + bv;
         }
         __syncthreads();
+        if (has) {
         float mx = -INFINITY;
         int am = 0x7fffffff;
         for (int c = j; c < C; c += 16) {
@@ -199,14 +209,15 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
             for (int c = j; c < C; c += 16) fw.probs[(long)b * C + c] = lg[c] * rs;
         for (int c = j; c < kDhCP; c += 16)
             lg[c] = (live && c < C) ? (lg[c] * rs - (c == y ? 1.f : 0.f)) * coef * fw.grad_scale : 0.f;
+        }
     }
     __syncthreads();
 
     // ---- head backward: dd1 tiles (gated by the Dense layer's ReLU6), its column sums = the Dense bias gradient, dW2 tiles, db2 ----
-    f32x4 accw[6];
+    f32x4 accw[WT];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) accw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int nt = wave; nt < K / 16; nt += 4) {
+    for (int q = 0; q < WT; ++q) accw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = wave; nt < K / 16; nt += NW) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < kDhCP / 4; ++j) acc = mfma16(ds[li * kDhCS + 4 * j + lq], ws[(16 * nt + li) * kDhCS + 4 * j + lq], acc);
@@ -226,8 +237,8 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
         if (lq == 0) atomicAdd(g.ddb + 16 * nt + li, cs);
     }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int t = wave + 4 * q, mt = t / 3, nt = t - 3 * mt;            // (K / 16) x 3 = 24 tiles, six per wave
+    for (int q = 0; q < WT; ++q) {
+        const int t = wave + NW * q, mt = t / 3, nt = t - 3 * mt;           // (K / 16) x 3 = 24 tiles, WT per wave
 #pragma unroll
         for (int j = 0; j < 4; ++j) accw[q] = mfma16(xs[(4 * j + lq) * kDhKS + 16 * mt + li], ds[(4 * j + lq) * kDhCS + 16 * nt + li], accw[q]);
     }
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
             for (int r = 0; r < 4; ++r)
                 if (b0 + 4 * lq + r < g.B) za[r] = g.zmax4[(long)(b0 + 4 * lq + r) * g.flat + 16 * wave + li];
         for (int i = 0; i < tpw; ++i) {
-            const int nt = wave + 4 * i, tap = nt / (kDhK / 16), ctl = nt - tap * (kDhK / 16);   // flat column tile -> (tap, 16-channel tile)
+            const int nt = wave + NW * i, tap = nt / (kDhK / 16), ctl = nt - tap * (kDhK / 16);  // flat column tile -> (tap, 16-channel tile)
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
             bf16x8 b[4][3];
 #pragma unroll
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
             if (g.acc4 && i + 1 < tpw)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (b0 + 4 * lq + r < g.B) zan[r] = g.zmax4[(long)(b0 + 4 * lq + r) * g.flat + 16 * (nt + 4) + li];
+                    if (b0 + 4 * lq + r < g.B) zan[r] = g.zmax4[(long)(b0 + 4 * lq + r) * g.flat + 16 * (nt + NW) + li];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) acc = mfma_bf16x6(a[kk], b[kk], acc);
             if (g.acc4) {
@@ -294,15 +305,15 @@ __global__ __launch_bounds__(256) void dense_head_fused_kernel(DenseHeadArgs g)
     }
     // gather the dense (K x C) block of dW2 in LDS so that the float atomics of a wave-instruction hit 64 contiguous addresses
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int t = wave + 4 * q, mt = t / 3, nt = t - 3 * mt, c = 16 * nt + li;
+    for (int q = 0; q < WT; ++q) {
+        const int t = wave + NW * q, mt = t / 3, nt = t - 3 * mt, c = 16 * nt + li;
         if (c < C) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) ws[(16 * mt + 4 * lq + r) * C + c] = accw[q][r];
         }
     }
     __syncthreads();
-    for (int i = tid; i < K * C; i += 256) atomicAdd(g.dw2 + i, ws[i]);
+    for (int i = tid; i < K * C; i += NT) atomicAdd(g.dw2 + i, ws[i]);
     if (tid < C) atomicAdd(g.db2 + tid, accb);
 }
 

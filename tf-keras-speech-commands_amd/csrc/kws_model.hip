@@ -360,7 +360,7 @@ static bool group_fwd_ok(const kws_model *m)
 // (kws_dense_head.h), whose Dense weights are fragment-major in both orders
 static bool dense_head_fused_ok(const kws_model *m, int mprec)
 {
-    return m->kind == KWS_SIMPLE_CNN && mprec == 1 && !m->deterministic && head_bwd_fuses(m) && m->head_K == kDhK && m->d.flat % 64 == 0 &&
+    return m->kind == KWS_SIMPLE_CNN && mprec == 1 && !m->deterministic && head_bwd_fuses(m) && m->head_K == kDhK && m->d.flat % (16 * kDhWaves) == 0 &&
            m->d.flat <= 1024;
 }
 static SplitDescs split_descs(const kws_model *m, const float *params, CnnWs &w, bool group_fwd = false, bool dense_fused = false)
@@ -807,7 +807,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             da.fw = HeadFwdArgs{params + m->o_hb, a->labels, a->class_weights, a->probs, w.loss_i, w.correct_i, a->grad_scale / (float)B, a->ignore_index};
             const size_t smem = sizeof(float) * (size_t)(16 * (d.flat + 8) + 2 * 16 * kDhKS + 16 * kDhCS + kDhK * kDhCS);
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(dense_head_fused_kernel), (int)smem)) return rc;
-            KWS_LAUNCH("dense_head_fused_kernel", dense_head_fused_kernel, dim3(blocks_for(B, 16)), dim3(256), smem, s, da);
+            KWS_LAUNCH("dense_head_fused_kernel", dense_head_fused_kernel, dim3(blocks_for(B, 16)), dim3(kDhThreads), smem, s, da);
             dense_fused = true;
         } else if (fused_head) {
             const kws_train_args *a = fused_head;

@@ -99,9 +99,12 @@ def main():
     names = args or list(SETS)
     path = os.path.join(OUT, "r03_pmc.json")
     out = {}
-    if os.path.exists(path):
-        with open(path) as f:
-            out = json.load(f)
+    # start from the published records (gpurun_out/ is empty on a fresh GPU box): a run over some workloads keeps the others
+    for src in (path, os.path.join(ROOT, "profiles", "r03_pmc.json")):
+        if os.path.exists(src):
+            with open(src) as f:
+                out = json.load(f)
+            break
     from kws_amd import lib
     bid = lib.build_id()
     out["_how"] = __doc__

@@ -591,6 +591,40 @@ def test_lstm_host_api_fit_learns(torch):
     assert m.predict(x[:7]).shape == (7, C)
 
 
+def test_cnn_accumulator_sets_alternate_and_are_left_clean(torch):
+    """The default train step keeps its BatchNorm sums in accumulator sets that alternate between consecutive passes and are cleared by
+    the consumer of the OTHER parity (kws_device.h: acc_add): the same batch three times in a row, with other batch sizes in between and
+    with a deterministic (partial-sum) pass in between, must give the same gradients and batch statistics every time -- a set that was not
+    cleared would add the previous pass's sums."""
+    C = 9
+    _, dm = build("simple_cnn", C, seed=5)
+    x = torch.from_numpy(features(96, 71)).cuda()
+    y = torch.from_numpy(np.random.default_rng(72).integers(0, C, 96).astype(np.int32)).cuda()
+    others = [(features(n, 80 + n), np.random.default_rng(n).integers(0, C, n).astype(np.int32)) for n in (5, 33, 200)]
+    state0 = dm.state.clone()
+    ref = None
+    for rnd in range(4):
+        dm.state.copy_(state0)                      # the moving statistics are part of what the consumers' block 0 writes
+        dm.train_fwd_bwd(x, y, dropout_seed=11)
+        torch.cuda.synchronize()
+        got = (dm.grads.clone(), dm.state.clone(), float(dm.stats[0].item()))
+        if ref is None:
+            ref = got
+        else:
+            scale = float(ref[0].abs().max())
+            assert float((got[0] - ref[0]).abs().max()) < 2e-5 * scale, rnd        # float / double atomics: order noise only
+            assert torch.allclose(got[1], ref[1], rtol=1e-6, atol=1e-7), rnd
+            assert abs(got[2] - ref[2]) < 1e-3, rnd
+        xo, yo = others[rnd % len(others)]
+        dm.train_fwd_bwd(torch.from_numpy(xo).cuda(), torch.from_numpy(yo).cuda(), dropout_seed=12 + rnd)
+        if rnd == 1:                                # one pass of the deterministic form in between (it does not touch the sets)
+            dm.set_deterministic(True)
+            dm.train_fwd_bwd(x, y, dropout_seed=11)
+            dm.set_deterministic(False)
+        if rnd == 2:                                # and an inference forward
+            dm.forward(x)
+
+
 @pytest.mark.parametrize("B", [1, 3, 17, 65, 97, 193])
 def test_cnn_train_odd_batch_sizes(torch, B):
     """Batches that do not fill the kernels' tiles (96- and 64-row blocks of the split-precision products, 4 clips per

@@ -591,16 +591,16 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     // finalize-free batch statistics (kws_device.h: acc_add), non-deterministic training at the default geometry: conv2 .. conv4 add their
     // sums to accumulator sets and the next kernel of the chain derives scale / shift in its prologue -- three launches less
     const bool acc_fwd = fuse_pool2 && !m->deterministic && kCh[4] <= 128;
-    unsigned fpar = 0;
+    unsigned fpar[4] = {0, 0, 0, 0};
     if (acc_fwd) {
         if (!R) R = const_cast<kws_model *>(m)->dev_res();
         if (!R) return fail(KWS_ERR_HIP, "cannot create the model's side stream / events on this device");
-        fpar = R->fwd_passes++;
+        for (int l = 1; l < 4; ++l) fpar[l] = R->acc_uses[0][l]++;
         KWS_TRY(acc_make_clean(R, s));
         R->acc_dirty = true;               // until every kernel of this pass is enqueued
     }
     auto acc_in = [&](int l) {             // the consumer's view of layer l's statistics
-        return BnAccFwd{acc_set(R, 0, l, fpar), acc_set(R, 0, l, fpar + 1), (long)B * Hz[l] * Wz[l], params + m->o_g[l], params + m->o_b[l],
+        return BnAccFwd{acc_set(R, 0, l, fpar[l]), acc_set(R, 0, l, fpar[l] + 1), (long)B * Hz[l] * Wz[l], params + m->o_g[l], params + m->o_b[l],
                         state + m->o_mm[l], state + m->o_mv[l], coef_of(w.coef[l], kCh[l + 1])};
     };
     for (int l = 1; l < 4; ++l) {
@@ -616,7 +616,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             const size_t smb = std::max((size_t)6 * 16 * (((Hs[1] + 2) * (Ws[1] + 2) + 15) & ~15), sizeof(double) * 4 * 2 * 16);
             if (training && bf16) {
                 KWS_LAUNCH("conv_fwd_clip_bf16<16,32>", (conv_fwd_clip_bf16_kernel<true>), dim3(nblk), dim3(256), smb, s, in, kern, w.z[1], B, Hs[1],
-                           Ws[1], w.partial, kStatStride, nullptr, nullptr, acc_fwd ? acc_set(R, 0, 1, fpar) : nullptr);
+                           Ws[1], w.partial, kStatStride, nullptr, nullptr, acc_fwd ? acc_set(R, 0, 1, fpar[1]) : nullptr);
                 fused_stat_blocks = (int)nblk;
             } else if (training) {
                 KWS_LAUNCH("conv_fwd_clip<16,32>", (conv_fwd_clip_kernel<32, true>), dim3(nblk), dim3(256), sm, s, in, kern, w.z[1], B, Hs[1], Ws[1],
@@ -649,7 +649,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             if (bf16 && training && !prep_in_stats) KWS_HIP_CHECK(hipStreamWaitEvent(s, R->ev[11], 0));     // the weight planes are ready
             // the split-precision kernels write the BatchNorm partial sums from their epilogue when training
             if (group_fwd) {
-                if (acc_fwd) { const BnAccFwd in2 = acc_in(1); fused_stat_blocks = launch_group_conv3(m, B, w, s, fuse_pool2, &in2, acc_set(R, 0, 2, fpar)); }
+                if (acc_fwd) { const BnAccFwd in2 = acc_in(1); fused_stat_blocks = launch_group_conv3(m, B, w, s, fuse_pool2, &in2, acc_set(R, 0, 2, fpar[2])); }
                 else fused_stat_blocks = launch_group_conv3(m, B, w, s, fuse_pool2);
                 if (fused_stat_blocks < 0) return fused_stat_blocks;
             } else if (bf16) {
@@ -661,7 +661,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
             // activation='relu', cnn.py:55
             if (group_fwd) {
                 // forms a3 = relu6(BN3(z3)) while staging, like the ABN form below
-                if (acc_fwd) { const BnAccFwd in3 = acc_in(2); fused_stat_blocks = launch_group_conv4(m, B, w, s, &in3, acc_set(R, 0, 3, fpar)); }
+                if (acc_fwd) { const BnAccFwd in3 = acc_in(2); fused_stat_blocks = launch_group_conv4(m, B, w, s, &in3, acc_set(R, 0, 3, fpar[3])); }
                 else fused_stat_blocks = launch_group_conv4(m, B, w, s);
                 if (fused_stat_blocks < 0) return fused_stat_blocks;
             } else if (bf16) {
@@ -773,7 +773,8 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     const bool acc_bn2 = group_bwd && !det && routed_bwd2 && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
     const bool acc_bn3 = group_bwd && !det;
     const bool acc_bn4 = fused_head && dense_head_fused_ok(m, mprec) && !det && kCh[4] == kDhK && d.flat == d.H4 * d.W4 * kCh[4];
-    const unsigned par = R->bwd_passes++;
+    // parity of each layer's sets: flipped only by a pass that uses them (its consumer is what clears the other parity)
+    const unsigned bpar[4] = {0u, acc_bn2 ? R->acc_uses[1][1]++ : 0u, acc_bn3 ? R->acc_uses[1][2]++ : 0u, acc_bn4 ? R->acc_uses[1][3]++ : 0u};
     KWS_TRY(acc_make_clean(R, s));
     R->acc_dirty = true;               // until every kernel of this pass is enqueued
     // head: dW2, db2, dd1 (gated by dense's ReLU6)
@@ -793,11 +794,11 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             da.d1 = w.d1; da.dd1 = w.dd1; da.da4 = w.da4; da.dw2 = grads + m->o_hk; da.db2 = grads + m->o_hb; da.ddb = grads + m->o_db;
             da.B = B; da.C = m->C; da.flat = d.flat;
             if (acc_bn4) {
-                da.zmax4 = w.zmax4; da.coef4 = coef_of(w.coef[3], 128).scale; da.acc4 = acc_set(R, 1, 3, par);
+                da.zmax4 = w.zmax4; da.coef4 = coef_of(w.coef[3], 128).scale; da.acc4 = acc_set(R, 1, 3, bpar[3]);
                 da.drop_rate = seed != 0 ? 0.5f : 0.f; da.seed_lo = slo; da.seed_hi = shi;
             }
             if (R->pool4_pending) {             // the forward pass of this step left layer 4's activation to this kernel
-                const unsigned fpar = R->fwd_passes - 1;
+                const unsigned fpar = R->acc_uses[0][3] - 1;
                 da.z4 = w.z[3]; da.a4w = w.a[3]; da.zmax4w = w.zmax4; da.arg4w = w.arg4; da.H3 = Hz[3]; da.W3 = Wz[3];
                 da.in4 = BnAccFwd{acc_set(R, 0, 3, fpar), acc_set(R, 0, 3, fpar + 1), (long)B * Hz[3] * Wz[3], params + m->o_g[3], params + m->o_b[3],
                                   R->pool4_mm, R->pool4_mv, coef_of(w.coef[3], 128)};
@@ -890,7 +891,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
         // conv2's early weight gradient forks right behind this finalize kernel
         const bool wgrad_early_l1 = compact_g && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
         const bool acc_l = (l == 1 && acc_bn2) || (l == 2 && acc_bn3 && fused_bn3_blocks > 0) || (l == 3 && acc_bn4);
-        const BnAccBwd ab{acc_set(R, 1, l, par), acc_set(R, 1, l, par + 1), M, grads + m->o_g[l], grads + m->o_b[l]};
+        const BnAccBwd ab{acc_set(R, 1, l, bpar[l]), acc_set(R, 1, l, bpar[l] + 1), M, grads + m->o_g[l], grads + m->o_b[l]};
         if (acc_l) ;                                            // the consumers derive k2 / k3 themselves (layer 2: fork(1) was armed in front of conv3's data gradient)
         else {
             if (l == 1 && wgrad_early_l1) arm(1);
@@ -935,7 +936,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (comm) KWS_TRY(comm_allreduce_early(comm, grads + m->o_k[3], m->P - m->o_k[3], s2));
             if (bucket_event) KWS_HIP_CHECK(hipEventRecord(bucket_event, s2));
             if (group_bwd) {
-                fused_bn3_blocks = launch_group_dgrad4(m, B, w, s, acc_bn3 ? acc_set(R, 1, 2, par) : nullptr);
+                fused_bn3_blocks = launch_group_dgrad4(m, B, w, s, acc_bn3 ? acc_set(R, 1, 2, bpar[2]) : nullptr);
                 if (fused_bn3_blocks < 0) return fused_bn3_blocks;
             } else if (mprec == 1 && blocks_for((long)B * Hs[3] * Ws[3], 64) <= (unsigned)kStatStride) {
                 // the data gradient's epilogue is BatchNorm 3's backward reduction (conv3 has no pooling): it gates by ReLU6(y3), stores
@@ -953,7 +954,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             else KWS_TRY(launch_wgrad<32, 64, 3>(in, w.gz[2], dk, g, s2, det));
             if (group_bwd) {
                 if (acc_bn2) arm(1);                            // the last kernel in front of conv2's early weight-gradient fork
-                KWS_TRY(launch_group_dgrad3(m, B, w, s, acc_bn2 ? acc_set(R, 1, 1, par) : nullptr));
+                KWS_TRY(launch_group_dgrad3(m, B, w, s, acc_bn2 ? acc_set(R, 1, 1, bpar[1]) : nullptr));
             }
             else KWS_TRY(launch_dgrad<64, 32, 2>(w.gz[2], kern, w.da[1], g, s));
         } else {
@@ -970,9 +971,9 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             if (compact_g) { bn.gw = w.da[1]; bn.arg = routed_bwd2 ? w.arg2 : reinterpret_cast<const unsigned char *>(w.da[2]); }
             BnBwdArgs bn_w = bn;                                // the weight gradient's copy: it only reads the accumulator set
             if (acc_bn2) {
-                bn.acc = bn_w.acc = acc_set(R, 1, 1, par);
+                bn.acc = bn_w.acc = acc_set(R, 1, 1, bpar[1]);
                 bn.M = bn_w.M = M;
-                bn.acc_clear_set = acc_set(R, 1, 1, par + 1);
+                bn.acc_clear_set = acc_set(R, 1, 1, bpar[1] + 1);
                 bn.dgamma = grads + m->o_g[1]; bn.dbeta = grads + m->o_b[1]; bn.k2w = k.k2; bn.k3w = k.k3;
             }
             const bool wgrad_bf16 = mprec == 1 && H1 * W1 <= 160;

@@ -24,9 +24,10 @@ struct ModelRes {
     hipStream_t side = nullptr;
     hipEvent_t ev[16] = {nullptr};
     // BatchNorm sum accumulators of the finalize-free train step (kws_device.h: acc_add): [pass 0 = forward, 1 = backward][layer 0..3]
-    // [parity][kAccDoubles] doubles, zero at creation; a pass uses the sets of its parity and clears the other one
+    // [parity][kAccDoubles] doubles, zero at creation; a pass uses the sets of its parity and its consumers clear the other one
     double *acc = nullptr;
-    unsigned fwd_passes = 0, bwd_passes = 0;
+    unsigned acc_uses[2][4] = {};       // passes that USED the sets of (pass, layer): the parity of the next one (a pass that keeps the
+                                        // partial-sum form -- deterministic mode, another geometry -- must not flip it: it clears nothing)
     bool acc_dirty = false;             // an enqueue failed half-way: clear everything before the next pass
     bool pool4_pending = false;         // the forward pass left layer 4's activation to the fused Dense + head kernel of the backward pass
     float *pool4_mm = nullptr, *pool4_mv = nullptr;     // ... and these are BatchNorm-4's moving statistics it will update

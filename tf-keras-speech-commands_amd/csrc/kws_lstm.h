@@ -28,8 +28,12 @@ template <int KX, bool SAVE>
 __global__ __launch_bounds__(kLstmFwdThreads) void lstm_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ Wk,
                                                                     const float *__restrict__ Uk, const float *__restrict__ bias,
                                                                     float *__restrict__ h_out, float *__restrict__ saved, int B, int T,
-                                                                    int F, float drop_rate, uint32_t slo, uint32_t shi)
+                                                                    int F, float drop_rate, uint32_t slo, uint32_t shi, float *__restrict__ zero_buf = nullptr, long zero_n = 0)
 {
+    // training: the gradient buffer of the backward pass that follows is cleared here (zero_n floats over the whole grid) instead of by a
+    // memset node on the step's chain
+    if (zero_buf)
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (long)gridDim.x * blockDim.x) zero_buf[i] = 0.f;
     extern __shared__ float gsm[];
     const int XS = gru_xstride(T, F);
     float *xs = gsm;                       // [16][XS]

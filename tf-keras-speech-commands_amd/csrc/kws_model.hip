@@ -1277,6 +1277,13 @@ int run_head(const kws_model *m, int B, const float *params, const float *x, flo
     return KWS_OK;
 }
 
+int run_loss_reduce(const float *loss_i, const float *correct_i, int B, float *stats, hipStream_t s)
+{
+    KWS_LAUNCH("loss_reduce_kernel", loss_reduce_kernel, dim3(1), dim3(256), 0, s, loss_i, correct_i, B, stats);
+    KWS_LAUNCH_CHECK("loss sums");
+    return KWS_OK;
+}
+
 bool head_bwd_fuses(const kws_model *m) { return m->head_K % 16 == 0 && m->head_K <= 128 && m->C <= 48; }
 
 int run_head_bwd(const kws_model *m, int B, const float *params, const float *x, const float *dlogits, float *dx,
@@ -1296,9 +1303,13 @@ int run_head_bwd(const kws_model *m, int B, const float *params, const float *x,
         constexpr int G = 1;                          // 16-sample groups per block (4 measured slower: 64 blocks expose each group's staging latency)
         const size_t smem_fast = sizeof(float) * (size_t)(16 * (K + 2) + (16 + K) * 50);
         if (fwd) {          // the train step's fused form: forward + loss + both backward products (kws_layers.h)
-            if (!relu6_gate || deterministic) return fail(KWS_ERR_INVALID, "the fused head kernel serves the non-deterministic train step of simple_cnn");
-            KWS_LAUNCH("head_fwd_bwd_kernel", (head_bwd_mfma_kernel<true, 1, true>), dim3(blocks_for(B, 16)), dim3(256), smem_fast, s, x, params + m->o_hk,
-                       nullptr, dx, dw2, db2, B, K, m->C, dx_colsum, nullptr, nullptr, nullptr, *fwd);
+            if (deterministic) return fail(KWS_ERR_INVALID, "the fused head kernel serves the non-deterministic train steps");
+            if (relu6_gate)
+                KWS_LAUNCH("head_fwd_bwd_kernel", (head_bwd_mfma_kernel<true, 1, true>), dim3(blocks_for(B, 16)), dim3(256), smem_fast, s, x, params + m->o_hk,
+                           nullptr, dx, dw2, db2, B, K, m->C, dx_colsum, nullptr, nullptr, nullptr, *fwd);
+            else            // the recurrent models: no activation between the last hidden state and the head
+                KWS_LAUNCH("head_fwd_bwd_kernel", (head_bwd_mfma_kernel<false, 1, true>), dim3(blocks_for(B, 16)), dim3(256), smem_fast, s, x, params + m->o_hk,
+                           nullptr, dx, dw2, db2, B, K, m->C, dx_colsum, nullptr, nullptr, nullptr, *fwd);
             KWS_LAUNCH_CHECK("head forward + backward");
             return KWS_OK;
         }

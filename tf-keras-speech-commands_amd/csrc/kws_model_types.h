@@ -109,6 +109,9 @@ int run_head_bwd(const kws_model *m, int B, const float *params, const float *x,
                  float *grads, bool relu6_gate, hipStream_t s, float *dx_colsum = nullptr, const float *loss_i = nullptr,
                  const float *correct_i = nullptr, float *stats = nullptr, bool deterministic = false, const HeadFwdArgs *fwd = nullptr);
 
+// stats[0 .. 1] = the sums of the per-sample losses / correct flags, in a fixed order (loss_reduce_kernel)
+int run_loss_reduce(const float *loss_i, const float *correct_i, int B, float *stats, hipStream_t s);
+
 // simple_gru (kws_rnn.hip)
 size_t gru_workspace_bytes(const kws_model *m, int B, bool training);
 int gru_forward(kws_model *m, const float *feat, int B, const float *params, void *ws, size_t ws_bytes, float *probs,

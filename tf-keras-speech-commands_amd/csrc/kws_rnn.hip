@@ -39,7 +39,7 @@ int check(const kws_model *m, int B, bool training, void *ws, size_t ws_bytes, G
 
 template <int KX>
 int launch_fwd(const kws_model *m, const float *feat, int B, const float *params, GruWs &w, bool save, float rate, uint64_t seed,
-               hipStream_t s)
+               hipStream_t s, float *zero_buf, long zero_n)
 {
     const int T = m->n_features, F = m->feature_size;
     const size_t smem = gru_fwd_smem(T, F);
@@ -51,7 +51,7 @@ int launch_fwd(const kws_model *m, const float *feat, int B, const float *params
                 KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_fwd_kernel<KX, true>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             KWS_LAUNCH("lstm_fwd_kernel", (lstm_fwd_kernel<KX, true>), dim3(blocks_for(B, 16)), dim3(kLstmFwdThreads), smem, s, feat, params + m->o_rk,
-                       params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi);
+                       params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi, zero_buf, zero_n);
         } else {
             if (smem > 64 * 1024)
                 KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&lstm_fwd_kernel<KX, false>),
@@ -67,7 +67,7 @@ int launch_fwd(const kws_model *m, const float *feat, int B, const float *params
             KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gru_fwd_kernel<KX, true>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         KWS_LAUNCH("gru_fwd_kernel", (gru_fwd_kernel<KX, true>), dim3(blocks_for(B, 16)), dim3(kGruFwdThreads), smem, s, feat, params + m->o_rk,
-                   params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi);
+                   params + m->o_ru, params + m->o_rb, w.h_last, w.saved, B, T, F, rate, slo, shi, zero_buf, zero_n);
     } else {
         if (smem > 64 * 1024)
             KWS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gru_fwd_kernel<KX, false>),
@@ -106,12 +106,12 @@ int launch_bwd(const kws_model *m, const float *feat, int B, const float *params
 }
 
 int dispatch_fwd(const kws_model *m, const float *feat, int B, const float *params, GruWs &w, bool save, float rate, uint64_t seed,
-                 hipStream_t s)
+                 hipStream_t s, float *zero_buf = nullptr, long zero_n = 0)
 {
     const int kx = (m->feature_size + 3) / 4;
-    if (kx <= 5) return launch_fwd<5>(m, feat, B, params, w, save, rate, seed, s);
-    if (kx <= 10) return launch_fwd<10>(m, feat, B, params, w, save, rate, seed, s);
-    return launch_fwd<16>(m, feat, B, params, w, save, rate, seed, s);
+    if (kx <= 5) return launch_fwd<5>(m, feat, B, params, w, save, rate, seed, s, zero_buf, zero_n);
+    if (kx <= 10) return launch_fwd<10>(m, feat, B, params, w, save, rate, seed, s, zero_buf, zero_n);
+    return launch_fwd<16>(m, feat, B, params, w, save, rate, seed, s, zero_buf, zero_n);
 }
 
 int dispatch_bwd(const kws_model *m, const float *feat, int B, const float *params, float *grads, GruWs &w, float rate, uint64_t seed,
@@ -144,6 +144,24 @@ int gru_train_fwd_bwd(kws_model *m, const kws_train_args *a, hipStream_t s)
     int rc = check(m, a->B, true, a->ws, a->ws_bytes, w);
     if (rc) return rc;
     const float rate = a->dropout_seed != 0 ? 0.2f : 0.f;          // GRU / LSTM(dropout=0.2): input dropout, rnn.py:34-35,70-71
+    if (head_bwd_fuses(m)) {
+        // The recurrent kernel clears the gradient buffer in its own grid, and the head's forward pass (logits, softmax, loss, dlogits)
+        // runs inside its backward kernel (kws_layers.h: head_bwd_mfma_kernel<.., FWD>), as in the simple_cnn step: between the
+        // recurrent forward and backward kernels the chain is ONE launch instead of four (head forward, loss sums, memset, head backward)
+        rc = dispatch_fwd(m, a->feat, a->B, a->params, w, true, rate, a->dropout_seed, s, a->grads, (long)m->P);
+        if (rc) return rc;
+        const HeadFwdArgs hf{a->params + m->o_hb, a->labels, a->class_weights, a->probs, w.loss_i, w.correct_i, a->grad_scale / (float)a->B, a->ignore_index};
+        rc = run_head_bwd(m, a->B, a->params, w.h_last, nullptr, w.dh_last, a->grads, false, s, nullptr, nullptr, nullptr, nullptr, false, &hf);
+        if (rc) return rc;
+        if (a->overlap_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->overlap_event), s));
+        if (a->overlap_callback) a->overlap_callback(a->overlap_user);
+        if (a->forward_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->forward_event), s));
+        rc = dispatch_bwd(m, a->feat, a->B, a->params, a->grads, w, rate, a->dropout_seed, s);
+        if (rc) return rc;
+        if (a->stats) { rc = run_loss_reduce(w.loss_i, w.correct_i, a->B, a->stats, s); if (rc) return rc; }   // fixed-order sums of the per-sample values
+        if (a->bucket_event) KWS_HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(a->bucket_event), s));
+        return KWS_OK;
+    }
     rc = dispatch_fwd(m, a->feat, a->B, a->params, w, true, rate, a->dropout_seed, s);
     if (rc) return rc;
     rc = run_head(m, a->B, a->params, w.h_last, w.loss_i, w.correct_i, a->labels, a->class_weights, a->probs, nullptr, w.dlogits,

@@ -316,148 +316,154 @@ def kernel_roofline(workload, rep, n_launch, alg, L):
     return out
 
 
-def extra_workloads(torch, pr, feat_fn, reps):
+def extra_workloads(torch, pr, feat_fn, reps, which="all"):
     import kws_amd.lib as L
     from kws_amd.inference import InferenceSession
     from kws_amd.init import init_weights
     from kws_amd.model import DeviceModel, ModelSpec
     from kws_amd.pipeline import FeaturePipeline
     out = {}
-    # (v, run first: a fit() is what a fresh process of a user of the reference API does) the headline step behind the REFERENCE API: classifier.model.get_model(...).compile(...).fit(raw audio, batch_size=4096) -- the same
-    # pipelined step (kws_amd.pipeline: in-place gather + featurize of the next batch on a side stream), shuffled epochs over a resident set
-    from classifier.loss import SparseCategoricalCrossEntropy
-    from classifier.model import get_model
-    from common.model_utils import get_optimizer
-    nb = 48                                    # batches per epoch: 12.6 GB of float32 audio resident in HBM
-    wav_np, lab_np = synthetic_batch(4096, 0, N_CLASSES)
-    xs = torch.from_numpy(wav_np).cuda().repeat(nb, 1)
-    ys = torch.from_numpy(lab_np).cuda().repeat(nb)
-    m = get_model("simple_cnn", N_CLASSES)
-    m.compile(optimizer=get_optimizer("adam", 1e-3, decay_type=None), loss=SparseCategoricalCrossEntropy(), metrics=["accuracy"])
-    h = m.fit(xs, ys, batch_size=4096, epochs=3, verbose=0, shuffle=True)
-    cps = max(h.history["clips_per_sec"][1:])
-    log("extra: fit() %.4f ms/step" % (4096.0 / cps * 1e3))
-    out["fit_api_step"] = {"workload": "classifier.model.get_model('simple_cnn', 36).fit(raw audio (%d, 16000) resident in HBM, batch_size=4096, shuffle=True): "
-                                       "best epoch of 2 after a warm-up epoch, %d steps per epoch, wall clock incl. the epoch's host sync" % (xs.shape[0], nb),
-                           "ms_per_step": round(4096.0 / cps * 1e3, 4), "clips_per_s": round(cps, 1),
-                           "epochs_clips_per_s": [round(v, 1) for v in h.history["clips_per_sec"]]}
-    del xs, ys, m
-    torch.cuda.empty_cache()
-    # (i) featurize + simple_cnn inference forward, B = 4096: the north star's ">= 60 % of the HBM roofline" workload
-    wav_np, lab_np = synthetic_batch(4096, 0, N_CLASSES)
-    spec = ModelSpec("simple_cnn", N_CLASSES, pr.n_features, pr.feature_size)
-    dm = DeviceModel(spec)
-    dm.set_weights(init_weights(spec, seed=0))
-    s = InferenceSession(dm, feat_fn, 4096, use_graph=True)
-    s.wav.copy_(torch.from_numpy(wav_np))
-    ms = time_graph(s, reps, torch)
-    cps = 4096 / ms * 1e3
-    eager = InferenceSession(dm, feat_fn, 4096, use_graph=False)      # per-kernel times of the same forward, eager
-    eager.wav.copy_(s.wav)
-    L.prof_enable(True)
-    for _ in range(5):
-        eager.run()
-    rep = L.prof_report()
-    L.prof_enable(False)
-    log("extra: fwd_infer %.4f ms" % ms)
-    out["fwd_infer"] = {"workload": "featurize (f32 in) + simple_cnn inference forward, B = 4096, one hipGraph replay per batch", "ms": round(ms, 4),
-                        "clips_per_s": round(cps, 1), "hbm_roofline_clips_per_s": round(HBM_PEAK_GBS * 1e9 / FWD_BYTES_PER_CLIP, 1),
-                        "hbm_roofline_frac": round(cps * FWD_BYTES_PER_CLIP / (HBM_PEAK_GBS * 1e9), 4),
-                        "kernel_ms": {k: round(v["total_ms"] / 5, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}}
-    # the FLOP-side ceiling next to the HBM fraction: the summed pipe floors of the forward's kernels from the PMC record of this workload
-    fl = {}
-    for k in rep:
-        r, _ = pmc_record("infer" if not k.startswith("featurize") else "feat", k, L.build_id())
-        for n, v in floors_of(r, None).items():
-            if n.endswith("_floor_ms"):
-                fl[n] = round(fl.get(n, 0.0) + v, 5)
-    if fl:
-        out["fwd_infer"]["floors_ms_sum_over_kernels"] = fl
-        out["fwd_infer"]["compute_ceiling_clips_per_s"] = round(4096 / max(fl.get("compute_floor_ms", 0.0), 1e-9) * 1e3, 1)
-        out["fwd_infer"]["compute_ceiling_note"] = "sum over the forward's kernels of each kernel's largest pipe floor (vector ALU / LDS / matrix): what the counted work needs with perfect overlap inside every kernel and none between kernels"
-    del s, eager, dm
-    # (iii) simple_gru train step, B = 2048 (BASELINE configs[2]): featurize + fwd + bwd + Adam, pipelined like the headline step
-    B = 2048
-    wav_np, lab_np = synthetic_batch(B, 0, N_CLASSES)
-    wav, labels = torch.from_numpy(wav_np).cuda(), torch.from_numpy(lab_np).cuda()
-    spec = ModelSpec("simple_gru", N_CLASSES, pr.n_features, pr.feature_size)
-    dm = DeviceModel(spec)
-    dm.set_weights(init_weights(spec, seed=0))
-    from kws_amd.featurizer import Featurizer
-    # the recurrent step is light on LDS and registers: its pipeline keeps the featurizer's whole-chip configuration (same-box 0.306 ms
-    # per step with the shared-mode featurizer, 0.286 with this one)
-    pipe = FeaturePipeline(Featurizer(pr), B, pr.n_features, pr.feature_size, cu_share=2)
-    ev = torch.cuda.Event()
-
-    def gru_steps(n, k0):
-        pipe.submit(wav)
-        for i in range(n):
-            feat = pipe.take()
-            dm.train_fwd_bwd(feat, labels, dropout_seed=k0 + i + 1, overlap_event=ev,
-                             overlap_callback=(lambda: pipe.submit(wav, after=ev)) if i + 1 < n else None)
-            dm.adam_step(1e-3)
-
-    gru_steps(10, 0)
-    torch.cuda.synchronize()
-    nrep = 4 * reps
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    gru_steps(nrep, 100)
-    e1.record()
-    host_ms = (time.perf_counter() - t0) / nrep * 1e3
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / nrep * 1e3
-    log("extra: gru host enqueue %.4f ms/step, device %.4f ms/step" % (host_ms, e0.elapsed_time(e1) / nrep))
-    log("extra: gru_train %.4f ms" % ms)
-    out["gru_train"] = {"workload": "configs[2]: featurize + simple_gru fwd + bwd + Adam, B = 2048, 36 classes", "ms_per_step": round(ms, 4),
-                        "clips_per_s": round(B / ms * 1e3, 1), "final_loss": round(float(dm.stats[0].item()) / B, 4)}
-    # per-kernel times of the same pipelined execution, and the roofline of its kernels: the recurrence is 30 DEPENDENT steps per clip block
-    # (16 clips per block: 128 blocks at B = 2048, i.e. half of the 256 CUs), so the kernels are latency-bound; the figures say how far
-    L.prof_enable(True)
-    gru_steps(10, 1000)
-    torch.cuda.synchronize()
-    rep = L.prof_report()
-    L.prof_enable(False)
-    T, F, H = pr.n_features, pr.feature_size, 48
-    fwd_flops = 2.0 * B * T * (F * 3 * H + H * 3 * H)
-    out["gru_train"]["kernel_ms"] = {k: round(v["total_ms"] / 10, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}
-    out["gru_train"]["roofline"] = kernel_roofline("gru", rep, 10, {"gru_fwd_kernel": ("mfma", fwd_flops), "gru_bwd_kernel": ("mfma", 2.0 * fwd_flops + 2.0 * B * T * H * 3 * H),
-                                                                  "featurize_fft1024_f32": ("hbm", B * FEAT_BYTES_PER_CLIP)}, L)
-    del pipe, dm
-    # (iv) simple_cnn_lite fp16 inference, B = 16 384, hipGraph-captured featurize + forward (BASELINE configs[4])
-    B = 16384
-    spec = ModelSpec("simple_cnn_lite", N_CLASSES, pr.n_features, pr.feature_size)
-    lite = {}
-    wav_np, _ = synthetic_batch(B, 0, N_CLASSES)
-    for name, dt, nbytes in (("f32_in", torch.float32, 64144.0), ("pcm16_in", torch.int16, 32144.0)):
+    # `which`: one of fit / infer / gru / lite (bench.py runs every workload in a child process of its own: behind another workload in the same
+    # process the pipelined simple_gru step measured 0.210 ms against 0.168 ms alone -- the featurizer did not overlap the recurrent kernels)
+    if which in ("all", "fit"):
+        # (v, run first: a fit() is what a fresh process of a user of the reference API does) the headline step behind the REFERENCE API: classifier.model.get_model(...).compile(...).fit(raw audio, batch_size=4096) -- the same
+        # pipelined step (kws_amd.pipeline: in-place gather + featurize of the next batch on a side stream), shuffled epochs over a resident set
+        from classifier.loss import SparseCategoricalCrossEntropy
+        from classifier.model import get_model
+        from common.model_utils import get_optimizer
+        nb = 48                                    # batches per epoch: 12.6 GB of float32 audio resident in HBM
+        wav_np, lab_np = synthetic_batch(4096, 0, N_CLASSES)
+        xs = torch.from_numpy(wav_np).cuda().repeat(nb, 1)
+        ys = torch.from_numpy(lab_np).cuda().repeat(nb)
+        m = get_model("simple_cnn", N_CLASSES)
+        m.compile(optimizer=get_optimizer("adam", 1e-3, decay_type=None), loss=SparseCategoricalCrossEntropy(), metrics=["accuracy"])
+        h = m.fit(xs, ys, batch_size=4096, epochs=3, verbose=0, shuffle=True)
+        cps = max(h.history["clips_per_sec"][1:])
+        log("extra: fit() %.4f ms/step" % (4096.0 / cps * 1e3))
+        out["fit_api_step"] = {"workload": "classifier.model.get_model('simple_cnn', 36).fit(raw audio (%d, 16000) resident in HBM, batch_size=4096, shuffle=True): "
+                                           "best epoch of 2 after a warm-up epoch, %d steps per epoch, wall clock incl. the epoch's host sync" % (xs.shape[0], nb),
+                               "ms_per_step": round(4096.0 / cps * 1e3, 4), "clips_per_s": round(cps, 1),
+                               "epochs_clips_per_s": [round(v, 1) for v in h.history["clips_per_sec"]]}
+        del xs, ys, m
+        torch.cuda.empty_cache()
+    if which in ("all", "infer"):
+        # (i) featurize + simple_cnn inference forward, B = 4096: the north star's ">= 60 % of the HBM roofline" workload
+        wav_np, lab_np = synthetic_batch(4096, 0, N_CLASSES)
+        spec = ModelSpec("simple_cnn", N_CLASSES, pr.n_features, pr.feature_size)
         dm = DeviceModel(spec)
         dm.set_weights(init_weights(spec, seed=0))
-        s = InferenceSession(dm, feat_fn, B, wav_dtype=dt, use_graph=True, fp16=True)
-        src = torch.from_numpy(wav_np)
-        s.wav.copy_(src if dt == torch.float32 else (src * 32768.0).to(torch.int16))
-        ms = time_graph(s, max(5, reps // 2), torch)
-        log("extra: lite fp16 %s %.4f ms" % (name, ms))
-        lite[name] = {"ms": round(ms, 4), "clips_per_s": round(B / ms * 1e3, 1), "bytes_per_clip": nbytes,
-                      "hbm_roofline_frac": round(B / ms * 1e3 * nbytes / (HBM_PEAK_GBS * 1e9), 4)}
-        if name == "f32_in":
-            eager = InferenceSession(dm, feat_fn, B, wav_dtype=dt, use_graph=False, fp16=True)      # per-kernel times of the same forward, eager
-            eager.wav.copy_(s.wav)
-            L.prof_enable(True)
-            for _ in range(5):
-                eager.run()
-            torch.cuda.synchronize()
-            rep = L.prof_report()
-            L.prof_enable(False)
-            lite["kernel_ms"] = {k: round(v["total_ms"] / 5, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}
-            # algorithmic bytes: featurizer 64 000 in + 2 400 out; front kernel 2 400 in + 2 240 out (a2 as fp16); back kernel 2 240 in + 4 C out
-            lite["roofline"] = kernel_roofline("lite16", rep, 5, {"featurize_fft1024_f32": ("hbm", B * FEAT_BYTES_PER_CLIP),
-                                                                 "lite_front_infer_kernel": ("hbm", B * (2400.0 + 2240.0)),
-                                                                 "lite_back_f16_kernel": ("hbm", B * (2240.0 + 4.0 * N_CLASSES))}, L)
-            del eager
-        del s, dm
-    lite["workload"] = "configs[4]: featurize + simple_cnn_lite forward, fp16 activations / matrix operands with fp32 accumulation, B = 16384, one hipGraph replay per batch"
-    out["lite_fp16_graph"] = lite
+        s = InferenceSession(dm, feat_fn, 4096, use_graph=True)
+        s.wav.copy_(torch.from_numpy(wav_np))
+        ms = time_graph(s, reps, torch)
+        cps = 4096 / ms * 1e3
+        eager = InferenceSession(dm, feat_fn, 4096, use_graph=False)      # per-kernel times of the same forward, eager
+        eager.wav.copy_(s.wav)
+        L.prof_enable(True)
+        for _ in range(5):
+            eager.run()
+        rep = L.prof_report()
+        L.prof_enable(False)
+        log("extra: fwd_infer %.4f ms" % ms)
+        out["fwd_infer"] = {"workload": "featurize (f32 in) + simple_cnn inference forward, B = 4096, one hipGraph replay per batch", "ms": round(ms, 4),
+                            "clips_per_s": round(cps, 1), "hbm_roofline_clips_per_s": round(HBM_PEAK_GBS * 1e9 / FWD_BYTES_PER_CLIP, 1),
+                            "hbm_roofline_frac": round(cps * FWD_BYTES_PER_CLIP / (HBM_PEAK_GBS * 1e9), 4),
+                            "kernel_ms": {k: round(v["total_ms"] / 5, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}}
+        # the FLOP-side ceiling next to the HBM fraction: the summed pipe floors of the forward's kernels from the PMC record of this workload
+        fl = {}
+        for k in rep:
+            r, _ = pmc_record("infer" if not k.startswith("featurize") else "feat", k, L.build_id())
+            for n, v in floors_of(r, None).items():
+                if n.endswith("_floor_ms"):
+                    fl[n] = round(fl.get(n, 0.0) + v, 5)
+        if fl:
+            out["fwd_infer"]["floors_ms_sum_over_kernels"] = fl
+            out["fwd_infer"]["compute_ceiling_clips_per_s"] = round(4096 / max(fl.get("compute_floor_ms", 0.0), 1e-9) * 1e3, 1)
+            out["fwd_infer"]["compute_ceiling_note"] = "sum over the forward's kernels of each kernel's largest pipe floor (vector ALU / LDS / matrix): what the counted work needs with perfect overlap inside every kernel and none between kernels"
+        del s, eager, dm
+    if which in ("all", "gru"):
+        # (iii) simple_gru train step, B = 2048 (BASELINE configs[2]): featurize + fwd + bwd + Adam, pipelined like the headline step
+        B = 2048
+        wav_np, lab_np = synthetic_batch(B, 0, N_CLASSES)
+        wav, labels = torch.from_numpy(wav_np).cuda(), torch.from_numpy(lab_np).cuda()
+        spec = ModelSpec("simple_gru", N_CLASSES, pr.n_features, pr.feature_size)
+        dm = DeviceModel(spec)
+        dm.set_weights(init_weights(spec, seed=0))
+        from kws_amd.featurizer import Featurizer
+        # the recurrent step is light on LDS and registers: its pipeline keeps the featurizer's whole-chip configuration (same-box 0.306 ms
+        # per step with the shared-mode featurizer, 0.286 with this one)
+        pipe = FeaturePipeline(Featurizer(pr), B, pr.n_features, pr.feature_size, cu_share=2)
+        ev = torch.cuda.Event()
+
+        def gru_steps(n, k0):
+            pipe.submit(wav)
+            for i in range(n):
+                feat = pipe.take()
+                dm.train_fwd_bwd(feat, labels, dropout_seed=k0 + i + 1, overlap_event=ev,
+                                 overlap_callback=(lambda: pipe.submit(wav, after=ev)) if i + 1 < n else None)
+                dm.adam_step(1e-3)
+
+        gru_steps(10, 0)
+        torch.cuda.synchronize()
+        nrep = 4 * reps
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        gru_steps(nrep, 100)
+        e1.record()
+        host_ms = (time.perf_counter() - t0) / nrep * 1e3
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / nrep * 1e3
+        log("extra: gru host enqueue %.4f ms/step, device %.4f ms/step" % (host_ms, e0.elapsed_time(e1) / nrep))
+        log("extra: gru_train %.4f ms" % ms)
+        out["gru_train"] = {"workload": "configs[2]: featurize + simple_gru fwd + bwd + Adam, B = 2048, 36 classes", "ms_per_step": round(ms, 4),
+                            "clips_per_s": round(B / ms * 1e3, 1), "final_loss": round(float(dm.stats[0].item()) / B, 4)}
+        # per-kernel times of the same pipelined execution, and the roofline of its kernels: the recurrence is 30 DEPENDENT steps per clip block
+        # (16 clips per block: 128 blocks at B = 2048, i.e. half of the 256 CUs), so the kernels are latency-bound; the figures say how far
+        L.prof_enable(True)
+        gru_steps(10, 1000)
+        torch.cuda.synchronize()
+        rep = L.prof_report()
+        L.prof_enable(False)
+        T, F, H = pr.n_features, pr.feature_size, 48
+        fwd_flops = 2.0 * B * T * (F * 3 * H + H * 3 * H)
+        out["gru_train"]["kernel_ms"] = {k: round(v["total_ms"] / 10, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}
+        out["gru_train"]["roofline"] = kernel_roofline("gru", rep, 10, {"gru_fwd_kernel": ("mfma", fwd_flops), "gru_bwd_kernel": ("mfma", 2.0 * fwd_flops + 2.0 * B * T * H * 3 * H),
+                                                                      "featurize_fft1024_f32": ("hbm", B * FEAT_BYTES_PER_CLIP)}, L)
+        del pipe, dm
+    if which in ("all", "lite"):
+        # (iv) simple_cnn_lite fp16 inference, B = 16 384, hipGraph-captured featurize + forward (BASELINE configs[4])
+        B = 16384
+        spec = ModelSpec("simple_cnn_lite", N_CLASSES, pr.n_features, pr.feature_size)
+        lite = {}
+        wav_np, _ = synthetic_batch(B, 0, N_CLASSES)
+        for name, dt, nbytes in (("f32_in", torch.float32, 64144.0), ("pcm16_in", torch.int16, 32144.0)):
+            dm = DeviceModel(spec)
+            dm.set_weights(init_weights(spec, seed=0))
+            s = InferenceSession(dm, feat_fn, B, wav_dtype=dt, use_graph=True, fp16=True)
+            src = torch.from_numpy(wav_np)
+            s.wav.copy_(src if dt == torch.float32 else (src * 32768.0).to(torch.int16))
+            ms = time_graph(s, max(5, reps // 2), torch)
+            log("extra: lite fp16 %s %.4f ms" % (name, ms))
+            lite[name] = {"ms": round(ms, 4), "clips_per_s": round(B / ms * 1e3, 1), "bytes_per_clip": nbytes,
+                          "hbm_roofline_frac": round(B / ms * 1e3 * nbytes / (HBM_PEAK_GBS * 1e9), 4)}
+            if name == "f32_in":
+                eager = InferenceSession(dm, feat_fn, B, wav_dtype=dt, use_graph=False, fp16=True)      # per-kernel times of the same forward, eager
+                eager.wav.copy_(s.wav)
+                L.prof_enable(True)
+                for _ in range(5):
+                    eager.run()
+                torch.cuda.synchronize()
+                rep = L.prof_report()
+                L.prof_enable(False)
+                lite["kernel_ms"] = {k: round(v["total_ms"] / 5, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["total_ms"])}
+                # algorithmic bytes: featurizer 64 000 in + 2 400 out; front kernel 2 400 in + 2 240 out (a2 as fp16); back kernel 2 240 in + 4 C out
+                lite["roofline"] = kernel_roofline("lite16", rep, 5, {"featurize_fft1024_f32": ("hbm", B * FEAT_BYTES_PER_CLIP),
+                                                                     "lite_front_infer_kernel": ("hbm", B * (2400.0 + 2240.0)),
+                                                                     "lite_back_f16_kernel": ("hbm", B * (2240.0 + 4.0 * N_CLASSES))}, L)
+                del eager
+            del s, dm
+        lite["workload"] = "configs[4]: featurize + simple_cnn_lite forward, fp16 activations / matrix operands with fp32 accumulation, B = 16384, one hipGraph replay per batch"
+        out["lite_fp16_graph"] = lite
     torch.cuda.empty_cache()
     return out
 
@@ -528,7 +534,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the other SURVEY 8(d) workloads (extra.*)")
     ap.add_argument("--profile-steps", type=int, default=10)
-    ap.add_argument("--extra-only", action="store_true", help="(internal) run the SURVEY 8(d) side workloads and print their JSON")
+    ap.add_argument("--extra-only", nargs="?", const="all", default=None, choices=("all", "fit", "infer", "gru", "lite"),
+                    help="(internal) run the SURVEY 8(d) side workloads (or one of them) and print their JSON")
     ap.add_argument("--force-comm", action="store_true",
                     help="run the RCCL exchange (kws_allreduce_grads) even in a one-rank world: rehearsal of the N > 1 code path on one GPU")
     ap.add_argument("--overlap-point", type=int, default=-1,
@@ -551,7 +558,7 @@ def main():
         torch.cuda.set_device(0)
         from classifier.params import pr
         from kws_amd.featurizer import Featurizer
-        print(json.dumps(extra_workloads(torch, pr, Featurizer(pr), 30)))
+        print(json.dumps(extra_workloads(torch, pr, Featurizer(pr), 30, args.extra_only)))
         return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -745,12 +752,17 @@ def main():
         # hardware-queue assignment) that a user of that workload would not have.
         log("extra workloads (child process)")
         import subprocess
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--extra-only"], stdout=subprocess.PIPE, stderr=sys.stderr, timeout=420,
-                               text=True)
-            extra = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": "child exited %d" % r.returncode}
-        except (subprocess.TimeoutExpired, ValueError) as e:
-            extra = {"error": repr(e)}
+        extra = {}
+        for which in ("fit", "infer", "gru", "lite"):          # one process per workload (see extra_workloads)
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--extra-only", which], stdout=subprocess.PIPE, stderr=sys.stderr,
+                                   timeout=240, text=True)
+                if r.returncode == 0 and r.stdout.strip():
+                    extra.update(json.loads(r.stdout.strip().splitlines()[-1]))
+                else:
+                    extra["error_" + which] = "child exited %d" % r.returncode
+            except (subprocess.TimeoutExpired, ValueError) as e:
+                extra["error_" + which] = repr(e)
         extra["fp32_mfma_step"] = {"workload": "the headline train step with every matrix product on v_mfma_f32_16x16x4_f32 (bit-exact fp32 fma chains)",
                                    "ms_per_step": round(ms32, 4), "clips_per_s": round(B / ms32 * 1e3, 1)}
         extra["dense_head_mfma"] = dense_head

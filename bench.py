@@ -622,7 +622,7 @@ def main():
         for i in range(n):
             step_no[0] += 1
             feat, mom = pipe.take()
-            # next batch's features on the side stream, started at the step's overlap point (behind the last BatchNormalization's activation, include/kws.h): the library
+            # next batch's features on the side stream, started at the step's overlap point (behind conv3's forward kernel, include/kws.h): the library
             # records overlap_ev there and calls back, so the featurizer launch also sits at that point in HOST order
             # data parallel: the step exchanges its gradients itself (kws_train_args.comm): the early bucket (conv4 + dense + head,
             # 82 % of the bytes) on the model's side stream right behind conv4's weight gradient, the late bucket + BatchNormalization
@@ -785,7 +785,7 @@ def main():
                           "matrix_precision": "conv2/conv3/conv4/dense products as three-way bf16 splits on the bf16 matrix cores "
                                               "with fp32 accumulation (fp32-level error, kws_model_set_precision); conv1, conv3 "
                                               "data gradient, dense weight gradient and everything else fp32; extra.fp32_mfma_step is the all-fp32 number",
-                          "input_pipeline": "features of batch k+1 (and their second moments for layer 1, kws_feature_moments) computed on a side stream during step k, started behind the last BatchNormalization's activation kernel (kws_train_args.overlap_event, best robust point of eight swept; all K featurizations inside the timed region)",
+                          "input_pipeline": "features of batch k+1 (and their second moments for layer 1, kws_feature_moments) computed on a side stream during step k, started behind conv3's forward kernel (kws_train_args.overlap_event, best point of eleven swept, profiles/r03_overlap_sweep.txt; all K featurizations inside the timed region)",
                           "gradient_exchange": ("kws_train_args.comm (RCCL behind the C ABI): early bucket grads[%d:] on the model's side stream behind conv4's weight gradient, "
                                                 "late bucket + BN moving statistics grouped on the main stream behind the backward pass" % split) if comm is not None else "none (one rank)",
                           "allreduce_us": allreduce_us, "rccl_ranks": comm.world if comm is not None else 0,

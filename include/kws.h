@@ -286,7 +286,7 @@ int kws_model_get_precision(const kws_model *m, int *matrix, int *infer);
 int kws_model_set_deterministic(kws_model *m, int on);
 
 /* Tuning aid: where in the simple_cnn train step kws_train_args.overlap_event is recorded / overlap_callback is called.  -1 (default):
- * the library's choice (10 = behind conv3's forward); 6 behind the last BatchNormalization's activation kernel, 0 behind the last forward convolution, 1 behind
+ * the library's choice (10 = behind conv3's forward); 6 behind the last forward convolution's BatchNormalization statistics (its activation now rides in the Dense + head kernel), 0 behind the last forward convolution, 1 behind
  * the loss, 2 behind the head's backward kernel, 3 behind the dense data gradient, 4 behind BatchNorm-4's backward, 5 behind conv4's
  * data gradient, 7 behind the dense forward product, 8 behind layer 1's forward kernel, 9 behind conv2's forward, 10 behind conv3's.
  * Changes scheduling only, never results (tests/test_model_gpu.py). */

@@ -625,6 +625,25 @@ def test_cnn_accumulator_sets_alternate_and_are_left_clean(torch):
             dm.forward(x)
 
 
+def test_cnn_ticket_finalize_sees_every_block(torch):
+    """Layer 1's backward kernel ends with an atomic-ticket finalize (kws_layer1_fast.h): 1024 blocks add their sums to an accumulator set and
+    the block that draws the last ticket evaluates dW1 / dgamma1 / dbeta1.  300 identical steps at the BASELINE batch: a last block that
+    read the sums before every block's atomics had landed would show up as a gradient far from the first step's (the atomics' order alone
+    moves them by ~1e-6 of the largest entry)."""
+    C, B = 36, 4096
+    _, dm = build("simple_cnn", C, seed=3)
+    x = torch.from_numpy(features(B, 401)).cuda()
+    y = torch.from_numpy(np.random.default_rng(402).integers(0, C, B).astype(np.int32)).cuda()
+    dm.train_fwd_bwd(x, y, dropout_seed=9)
+    ref = dm.grads.clone()
+    scale = float(ref.abs().max())
+    worst = torch.zeros((), device="cuda")
+    for _ in range(300):
+        dm.train_fwd_bwd(x, y, dropout_seed=9)
+        worst = torch.maximum(worst, (dm.grads - ref).abs().max())
+    assert float(worst) < 2e-5 * scale, float(worst) / scale
+
+
 @pytest.mark.parametrize("B", [1, 3, 17, 65, 97, 193])
 def test_cnn_train_odd_batch_sizes(torch, B):
     """Batches that do not fill the kernels' tiles (96- and 64-row blocks of the split-precision products, 4 clips per

@@ -18,7 +18,7 @@ namespace kws {
 template <int H, int W>
 __global__ __launch_bounds__(256, 4) void l1f_bwd_onepass_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
                                                                const float *__restrict__ da1, BnCoef k, int B, int clips_per_wave,
-                                                               double *__restrict__ partial)
+                                                               double *__restrict__ partial, L1FinalizeArgs fin = L1FinalizeArgs{})
 {
     using R = L1Runs<H, W>;                            // quadrant q of every tile walks window rows RR q .. RR q + RR - 1 (kws_layer1.h)
     constexpr int WP = R::WP, Wp = R::Wp, NWIN = R::NWIN, NXS = R::NXS, HW = R::HW, NST = R::NST, RL = R::RL, RR = R::RR;
@@ -147,13 +147,67 @@ __global__ __launch_bounds__(256, 4) void l1f_bwd_onepass_kernel(const float *__
     sz += __shfl_xor(sz, 16, 64); sz += __shfl_xor(sz, 32, 64);
     if (lq == 0) { shs[wave][0][li] = s; shs[wave][1][li] = sz; }
     __syncthreads();
+    double mine = 0.0;                                   // this block's sum of row threadIdx.x (rows as l1_bwd_finalize_moments_kernel reads them)
     if (threadIdx.x < 9 * 16) {
         const int tp = threadIdx.x / 16, c = threadIdx.x % 16;
-        partial[(long)threadIdx.x * kStatStride + blockIdx.x] =
-            ((double)shg[0][c][tp] + (double)shg[1][c][tp]) + ((double)shg[2][c][tp] + (double)shg[3][c][tp]);
+        mine = ((double)shg[0][c][tp] + (double)shg[1][c][tp]) + ((double)shg[2][c][tp] + (double)shg[3][c][tp]);
     } else if (threadIdx.x < kL1BwdRows) {
         const int ee = threadIdx.x - 9 * 16, which = ee >> 4, c = ee & 15;
-        partial[(long)threadIdx.x * kStatStride + blockIdx.x] = (shs[0][which][c] + shs[1][which][c]) + (shs[2][which][c] + shs[3][which][c]);
+        mine = (shs[0][which][c] + shs[1][which][c]) + (shs[2][which][c] + shs[3][which][c]);
+    }
+    if (!fin.acc) {
+        if (threadIdx.x < kL1BwdRows) partial[(long)threadIdx.x * kStatStride + blockIdx.x] = mine;
+        return;
+    }
+    // No finalize launch (the last kernel of the step's main chain, 6.6 us of pure latency): every block ADDS its rows to an accumulator
+    // set (kws_device.h: acc_add; eight slots), takes a ticket, and the block that draws the last one evaluates
+    // l1_bwd_finalize_moments_kernel's closed forms from the sums, clears the set and the ticket counter for the next pass.  Only atomics
+    // carry data between the blocks (the sums are read back with agent-scope atomic loads).
+    // No __threadfence(): an agent-scope fence writes back and INVALIDATES the XCD's L2 -- with one per block the kernel took 165 us instead
+    // of 68 (every other block of the XCD lost its cached features).  The barrier's s_waitcnt vmcnt(0) has every wave's atomics acknowledged
+    // by the memory side before thread 0 draws the ticket, and the last block reads the sums back with agent-scope atomic loads.
+    if (threadIdx.x < kL1BwdRows) atomicAdd(fin.acc + (blockIdx.x & (kAccSlots - 1)) * kL1BwdRows + threadIdx.x, mine);
+    __syncthreads();
+    __shared__ unsigned last_block;
+    if (threadIdx.x == 0) last_block = atomicAdd(fin.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last_block) return;
+    __shared__ double rows[kL1BwdRows];
+    if (threadIdx.x < kL1BwdRows) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < kAccSlots; ++j) {
+            double *p = fin.acc + j * kL1BwdRows + threadIdx.x;
+            t += __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *p = 0.0;                                    // consumed by the next pass's kernels only
+        }
+        rows[threadIdx.x] = t;
+    }
+    if (threadIdx.x == 0) *fin.ticket = 0u;
+    __syncthreads();
+    if (threadIdx.x < 144 + 16) {
+        const int row = threadIdx.x, c = row < 144 ? row % 16 : row - 144;
+        const double sg = rows[144 + c], sgz = rows[160 + c];
+        const double M = fin.q[kMomCount - 1], inv = (double)k.inv[c];
+        double mean = 0.0;                               // the batch mean of z in double (the kernels centred with its float rounding)
+#pragma unroll
+        for (int u = 0; u < 9; ++u) mean += (double)wk[u * 16 + c] * fin.q[u * kMomN + 9];
+        mean /= M;
+        const double sgx = inv * (sgz + ((double)k.mean[c] - mean) * sg);      // sum g xhat = inv * sum g (z - mean)
+        if (row >= 144) {
+            fin.dbeta[c] = (float)sg;
+            fin.dgamma[c] = (float)sgx;
+            k.k2[c] = (float)(sg / M);
+            k.k3[c] = (float)(sgx / M);
+        } else {
+            const int t = row / 16;
+            double wq = 0.0;                             // sum_t' w[t'][c] Q[t'][t] = sum over pixels of z f(p+t)
+#pragma unroll
+            for (int u = 0; u < 9; ++u) wq += (double)wk[u * 16 + c] * fin.q[u * kMomN + t];
+            const double S = fin.q[t * kMomN + 9];
+            const double k1 = (double)fin.gamma[c] * inv, k2 = sg / M, k3 = sgx / M;
+            fin.dw[t * 16 + c] = (float)(k1 * (rows[row] - k2 * S - k3 * inv * (wq - mean * S)));
+        }
     }
 }
 

@@ -199,6 +199,10 @@ __global__ __launch_bounds__(256) void l1m_act_pool_moments_kernel(const float *
 //                                                cancels against mean * sum g and lost four digits in float per-clip partials)
 // to partial[row * kStatStride + blockIdx.x]; g = the gradient routed through max-pool and ReLU6 (same rule as every other pass).
 constexpr int kL1BwdRows = 9 * 16 + 32;
+// the finalize step of the one-pass backward kernel when it runs in the accumulator form (kws_layer1_fast.h): acc = [kAccSlots][kL1BwdRows]
+// doubles + the ticket counter, both zero between passes; q = the feature moments; outputs as l1_bwd_finalize_moments_kernel's
+struct L1FinalizeArgs { double *acc = nullptr; unsigned *ticket = nullptr; const double *q = nullptr; const float *gamma = nullptr;
+                        float *dw = nullptr, *dgamma = nullptr, *dbeta = nullptr; };
 __global__ __launch_bounds__(256, 4) void l1m_bwd_onepass_kernel(const float *__restrict__ feat, const float *__restrict__ wk,
                                                                const float *__restrict__ da1, BnCoef k, int B, int H, int W,
                                                                int clips_per_wave, double *__restrict__ partial)

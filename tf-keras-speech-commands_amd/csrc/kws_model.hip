@@ -1034,13 +1034,22 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             // one pass collects G, sum g, sum g z per block (double partials, fixed order); the closed forms of dW1, dgamma, dbeta use Q
             const double *q = moments ? moments : w.moments;
             // the default map (30 frames x 20 coefficients) has a fully unrolled form with its own window walk (kws_layer1_fast.h)
-            if (d.H0 == 30 && d.W0 == 20)
+            // non-deterministic mode, default map: the kernel's last block evaluates the closed forms itself (no finalize launch); layer 0's
+            // backward set of the model's accumulators holds the sums, its last word the ticket counter (kAccSlots * kL1BwdRows < kAccDoubles)
+            const bool fin_in_kernel = !det && d.H0 == 30 && d.W0 == 20;
+            if (fin_in_kernel) {
+                double *acc0 = acc_set(R, 1, 0, 0);
+                const L1FinalizeArgs fin{acc0, reinterpret_cast<unsigned *>(acc0 + kAccDoubles - 1), q, params + m->o_g[0], grads + m->o_k[0],
+                                         grads + m->o_g[0], grads + m->o_b[0]};
+                KWS_LAUNCH("l1m_bwd_onepass_kernel", (l1f_bwd_onepass_kernel<30, 20>), dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, cpw, w.partial, fin);
+            } else if (d.H0 == 30 && d.W0 == 20)
                 KWS_LAUNCH("l1m_bwd_onepass_kernel", (l1f_bwd_onepass_kernel<30, 20>), dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, cpw, w.partial);
             else
                 KWS_LAUNCH("l1m_bwd_onepass_kernel", l1m_bwd_onepass_kernel, dim3(nbm), dim3(256), smemm, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0, cpw,
                            w.partial);
-            KWS_LAUNCH("l1_bwd_finalize_moments_kernel", l1_bwd_finalize_moments_kernel, dim3(144 + 16), dim3(64), 0, s, w.partial, nbm, q, kern1,
-                       params + m->o_g[0], k1, grads + m->o_k[0], grads + m->o_g[0], grads + m->o_b[0]);
+            if (!fin_in_kernel)
+                KWS_LAUNCH("l1_bwd_finalize_moments_kernel", l1_bwd_finalize_moments_kernel, dim3(144 + 16), dim3(64), 0, s, w.partial, nbm, q, kern1,
+                           params + m->o_g[0], k1, grads + m->o_k[0], grads + m->o_g[0], grads + m->o_b[0]);
         } else {
             KWS_LAUNCH("l1_bwd_reduce_kernel", l1_bwd_reduce_kernel<16>, dim3(nb), dim3(256), smem1, s, feat, kern1, w.da[0], k1, B, d.H0, d.W0,
                        cpb, w.partial);

@@ -597,7 +597,11 @@ def main():
     from kws_amd.pipeline import FeaturePipeline
     # the pipeline's featurizer shares the chip with the train step (half of each CU's LDS, FeaturePipeline sets it), so it is
     # its own object: feat_fn keeps the whole chip for the stand-alone workloads under `extra`
-    pipe = FeaturePipeline(Featurizer(pr), B, pr.n_features, pr.feature_size, moments=True)   # + kws_feature_moments behind the featurizer
+    # cu_share=2 (the whole-chip configuration of the featurizer) since round 3's overlap point: behind conv3's forward the featurizer does
+    # not really SHARE the CUs -- its blocks (336 of a SIMD's 512 registers) exclude conv4's forward (352) and the Dense + head kernel (224),
+    # device-clock stamps show conv4 forward -> featurizer -> Dense + head one after the other -- so it may as well run in its faster
+    # configuration (0.088 against 0.096 ms): same-box 0.5412 -> 0.5375 ms per step
+    pipe = FeaturePipeline(Featurizer(pr), B, pr.n_features, pr.feature_size, moments=True, cu_share=2)   # + kws_feature_moments behind the featurizer
     # data path collective: the C ABI's RCCL communicator (csrc/kws_comm.hip), bootstrapped over the torch group's store.  Created
     # AFTER the model (whose side stream exists since DeviceModel()) and the pipeline's stream: HIP deals streams to hardware queues
     # in creation order and RCCL creates its own (include/kws.h: kws_model_bind_device)

@@ -304,9 +304,10 @@ class KWSModel(object):
             key = (local_max, is_audio, nf, fs)
             if getattr(self, "_pipe_key", None) != key:
                 from kws_amd.featurizer import Featurizer
-                # its own featurizer object: beside a train step it runs in the one-block-per-CU configuration (same bits)
+                # its own featurizer object (same bits in every configuration): the whole-chip configuration, as bench.py's pipeline -- at
+                # the step's overlap point the featurizer's blocks and the step's kernels exclude each other from the CUs anyway
                 self._pipe = FeaturePipeline(Featurizer(pr) if is_audio else None, max(1, local_max), nf, fs, device=xd.device,
-                                             moments=self.model_type == 'simple_cnn', labels=True)
+                                             moments=self.model_type == 'simple_cnn', labels=True, cu_share=2)
                 self._pipe_key = key
             pipe = self._pipe
         stats_all = torch.zeros((steps, 2), dtype=torch.float32, device=xd.device)     # one row per step: no per-step accumulation kernels

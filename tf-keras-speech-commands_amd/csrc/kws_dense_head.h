@@ -64,7 +64,13 @@ __global__ __launch_bounds__(kDhThreads) void dense_head_fused_kernel(DenseHeadA
     bf16x8 bcur[DT][3], bnext[DT][3];
 #pragma unroll
     for (int t = 0; t < DT; ++t) fu_load_b(g.fd, DT * wave + t, lane, bcur[t]);
-    for (int i = tid; i < K * kDhCP; i += NT) { const int k = i / kDhCP, c = i - k * kDhCP; ws[k * kDhCS + c] = c < C ? g.w2[(long)k * C + c] : 0.f; }
+    // W2 -> LDS: all of a thread's loads are issued here (one L2 round trip; a load -> LDS store loop was twelve dependent ones, most of the
+    // 9 us this kernel spent in front of its first product) and stored behind the tile's staging
+    constexpr int NW2 = kDhK * kDhCP / NT;
+    static_assert(kDhK * kDhCP % NT == 0, "whole rounds");
+    float w2v[NW2];
+#pragma unroll
+    for (int j = 0; j < NW2; ++j) { const int i = tid + j * NT, k = i / kDhCP, c = i - k * kDhCP; w2v[j] = c < C ? g.w2[(long)k * C + c] : 0.f; }
     __shared__ __attribute__((aligned(16))) float cf4[4 * kDhK];   // z4: BatchNorm-4's scale | shift | mean | inv, derived here
     if (g.z4) {
         bn_fwd_coef_prologue(g.in4, kDhK, cf4, cf4 + kDhK, cf4 + 2 * kDhK, cf4 + 3 * kDhK);
@@ -122,6 +128,8 @@ __global__ __launch_bounds__(kDhThreads) void dense_head_fused_kernel(DenseHeadA
         if (b0 + r < g.B) v = *reinterpret_cast<const f32x4 *>(g.a4 + (long)(b0 + r) * g.flat + 4 * u);
         *reinterpret_cast<f32x4 *>(a4s + r * RS4 + 4 * u) = v;
     }
+#pragma unroll
+    for (int j = 0; j < NW2; ++j) { const int i = tid + j * NT, k = i / kDhCP, c = i - k * kDhCP; ws[k * kDhCS + c] = w2v[j]; }
     __syncthreads();
 
     // ---- Dense(128) + ReLU6: wave = column tiles DT wave .. DT wave + DT - 1 ----

@@ -859,7 +859,21 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const float *__restr
     float *ws = ds + 16 * CS;                       // [K][CS],  columns >= C are zero
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lq = lane >> 4;
     const int KT = K / 16;
-    for (int i = threadIdx.x; i < K * CP; i += 256) { const int k = i / CP, c = i - k * CP; ws[k * CS + c] = c < C ? w2[(long)k * C + c] : 0.f; }
+    {
+        // all of a thread's W2 loads first, then the LDS stores: one L2 round trip instead of up to 24 dependent ones (K <= 128)
+        constexpr int NWV = 128 * CP / 256;
+        float wv[NWV];
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int i = threadIdx.x + 256 * j, k = i / CP, c = i - k * CP;
+            wv[j] = (i < K * CP && c < C) ? w2[(long)k * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            const int i = threadIdx.x + 256 * j, k = i / CP, c = i - k * CP;
+            if (i < K * CP) ws[k * CS + c] = wv[j];
+        }
+    }
     f32x4 accw[MAXT];
 #pragma unroll
     for (int q = 0; q < MAXT; ++q) accw[q] = (f32x4){0.f, 0.f, 0.f, 0.f};

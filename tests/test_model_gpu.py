@@ -644,6 +644,27 @@ def test_cnn_ticket_finalize_sees_every_block(torch):
     assert float(worst) < 2e-5 * scale, float(worst) / scale
 
 
+@pytest.mark.parametrize("C", [49, 100])
+def test_cnn_train_more_classes_than_the_fused_head_takes(torch, C):
+    """More than 48 classes: the fused Dense + head kernel (and the MFMA head) do not apply, so the step runs the stand-alone head kernels,
+    layer 4's activation kernel in its accumulator form (bn_act_pool_acc_kernel) and the partial-sum form of BatchNorm-4's backward beside
+    the accumulator forms of layers 2 and 3 -- a mix no other test reaches.  Two consecutive steps against the oracle, dropout on."""
+    from oracle import model_oracle as mo
+    B = 40
+    om, dm = build("simple_cnn", C, seed=C)
+    x = features(B, 500 + C)
+    y = np.random.default_rng(C).integers(0, C, B)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
+    for step in range(2):
+        seed = 0xC0FFEE00 + C + step
+        loss, acc, p = mo.train_forward_backward(om, x.astype(np.float64), y, dropout_seed=seed)
+        probs = dm.train_fwd_bwd(xt, yt, dropout_seed=seed, want_probs=True)
+        np.testing.assert_allclose(probs.cpu().numpy(), p, atol=1e-4, rtol=0)
+        assert abs(float(dm.stats[0].item()) / B - loss) < 1e-4
+        for g, want, (li, n, _) in zip(dm.get_grads(), om.grad_list(), [w for w in om.weight_list() if w[2]]):
+            assert rel_err(g, want) < 3e-4, (C, step, li, n, rel_err(g, want))
+
+
 @pytest.mark.parametrize("B", [1, 3, 17, 65, 97, 193])
 def test_cnn_train_odd_batch_sizes(torch, B):
     """Batches that do not fill the kernels' tiles (96- and 64-row blocks of the split-precision products, 4 clips per

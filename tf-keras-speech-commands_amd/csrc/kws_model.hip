@@ -707,8 +707,8 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
                 KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_acc_kernel, dim3(std::min<unsigned>(1024u, blocks_for(total, 256))), dim3(256), 0, s,
                            w.z[l], acc_in(3), w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi, zm, ag);
             else
-            KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
-                               w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi, zm, ag);
+                KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<true>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,
+                           w.a[l], B, Hz[l], Wz[l], C, rate, slo, shi, zm, ag);
         } else if (!(l == 2 && a3_on_load)) {
             const long total = M * C;
             KWS_LAUNCH(prof_name("bn_act_pool_kernel", l + 1), bn_act_pool_kernel<false>, dim3(blocks_for(total, 256)), dim3(256), 0, s, w.z[l], k.scale, k.shift,

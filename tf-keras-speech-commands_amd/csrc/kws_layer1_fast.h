@@ -164,9 +164,11 @@ __global__ __launch_bounds__(256, 4) void l1f_bwd_onepass_kernel(const float *__
     // l1_bwd_finalize_moments_kernel's closed forms from the sums, clears the set and the ticket counter for the next pass.  Only atomics
     // carry data between the blocks (the sums are read back with agent-scope atomic loads).
     // No __threadfence(): an agent-scope fence writes back and INVALIDATES the XCD's L2 -- with one per block the kernel took 165 us instead
-    // of 68 (every other block of the XCD lost its cached features).  The barrier's s_waitcnt vmcnt(0) has every wave's atomics acknowledged
-    // by the memory side before thread 0 draws the ticket, and the last block reads the sums back with agent-scope atomic loads.
+    // of 68 (every other block of the XCD lost its cached features).  Instead every wave waits for the acknowledgement of its own atomics
+    // (s_waitcnt vmcnt(0): on gfx9 the counter covers atomics without return; the barrier alone does NOT wait for them) before the barrier
+    // behind which thread 0 draws the ticket, and the last block reads the sums back with agent-scope atomic loads.
     if (threadIdx.x < kL1BwdRows) atomicAdd(fin.acc + (blockIdx.x & (kAccSlots - 1)) * kL1BwdRows + threadIdx.x, mine);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ unsigned last_block;
     if (threadIdx.x == 0) last_block = atomicAdd(fin.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;

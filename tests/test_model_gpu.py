@@ -644,6 +644,38 @@ def test_cnn_ticket_finalize_sees_every_block(torch):
     assert float(worst) < 2e-5 * scale, float(worst) / scale
 
 
+def test_cnn_train_step_captured_in_a_graph_replays_correctly(torch):
+    """A train step captured into a hipGraph (tools/graphbench.py does that) must give the eager step's results on EVERY replay: the library
+    keeps the partial-sum BatchNorm forms under capture, because the accumulator sets' parity and the finalize ticket are state a replay does
+    not advance."""
+    C, B = 12, 256
+    _, dm = build("simple_cnn", C, seed=21)
+    x = torch.from_numpy(features(B, 601)).cuda()
+    y = torch.from_numpy(np.random.default_rng(602).integers(0, C, B).astype(np.int32)).cuda()
+    state0 = dm.state.clone()
+    dm.train_fwd_bwd(x, y, dropout_seed=5)
+    torch.cuda.synchronize()
+    ref, scale = dm.grads.clone(), float(dm.grads.abs().max())
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        dm.train_fwd_bwd(x, y, dropout_seed=5)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        dm.train_fwd_bwd(x, y, dropout_seed=5)
+    for rep in range(3):
+        dm.state.copy_(state0)
+        dm.grads.fill_(123.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert float((dm.grads - ref).abs().max()) < 2e-5 * scale, rep
+    dm.state.copy_(state0)
+    dm.train_fwd_bwd(x, y, dropout_seed=5)          # and the eager (accumulator) form still works afterwards
+    torch.cuda.synchronize()
+    assert float((dm.grads - ref).abs().max()) < 2e-5 * scale
+
+
 @pytest.mark.parametrize("C", [49, 100])
 def test_cnn_train_more_classes_than_the_fused_head_takes(torch, C):
     """More than 48 classes: the fused Dense + head kernel (and the MFMA head) do not apply, so the step runs the stand-alone head kernels,

@@ -79,7 +79,20 @@ void prof_events(const char *name, hipEvent_t *e0, hipEvent_t *e1);   // a fresh
 // launch took it; if no kernel followed, the caller records the event the plain way).  One armed event per host thread.
 struct ArmedEvent { hipEvent_t ev = nullptr; hipStream_t s = nullptr; hipEvent_t bound = nullptr; };
 ArmedEvent &armed_event();
-inline void arm_stop_event(hipEvent_t ev, hipStream_t s) { ArmedEvent &a = armed_event(); a.ev = ev; a.s = s; a.bound = nullptr; }
+// A stream that is being CAPTURED into a hipGraph gets no armed events: an event bound to a dispatch's completion signal is not a graph node,
+// so the waits on it would fall out of the capture (the side stream's kernels then ran once, eagerly, and every replay lacked them); the
+// callers fall back to hipEventRecord, which the capture turns into an edge.
+inline bool stream_is_capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return st != hipStreamCaptureStatusNone;
+}
+inline void arm_stop_event(hipEvent_t ev, hipStream_t s)
+{
+    if (stream_is_capturing(s)) return;
+    ArmedEvent &a = armed_event(); a.ev = ev; a.s = s; a.bound = nullptr;
+}
 // Scope guard of every function that arms events: whatever way the function is left (an early KWS_TRY / KWS_HIP_CHECK return between
 // arm_stop_event and the launch that should have carried the event), no armed event survives into an unrelated launch of this thread.
 struct DisarmOnExit { ~DisarmOnExit() { ArmedEvent &a = armed_event(); a.ev = nullptr; a.s = nullptr; a.bound = nullptr; } };

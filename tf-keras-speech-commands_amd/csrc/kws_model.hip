@@ -127,6 +127,9 @@ CnnWs carve_cnn(const kws_model *m, int B, bool training, unsigned char *base)
 }
 
 BnCoef coef_of(float *base, int C) { return BnCoef{base, base + C, base + 2 * C, base + 3 * C, base + 4 * C, base + 5 * C}; }
+// A train step that is being CAPTURED into a hipGraph keeps the partial-sum forms: the accumulator sets' parity and the ticket counter are
+// host-side / device-side state that a replay would not advance (the second replay would add to sums nobody cleared)
+static bool stream_capturing(hipStream_t s) { return stream_is_capturing(s); }
 // accumulator set of (pass, layer, parity) -- kws_model_types.h: ModelRes::acc
 static double *acc_set(ModelRes *R, int pass, int layer, unsigned parity) { return R->acc + ((size_t)(pass * 4 + layer) * 2 + (parity & 1u)) * kAccDoubles; }
 static int acc_make_clean(ModelRes *R, hipStream_t s)
@@ -590,7 +593,7 @@ int cnn_forward(const kws_model *m, const float *feat, int B, const float *param
     const bool fuse_pool2 = group_fwd && routed_bwd2 && d.H1 == kGrH1 && d.W1 == kGrW1;
     // finalize-free batch statistics (kws_device.h: acc_add), non-deterministic training at the default geometry: conv2 .. conv4 add their
     // sums to accumulator sets and the next kernel of the chain derives scale / shift in its prologue -- three launches less
-    const bool acc_fwd = fuse_pool2 && !m->deterministic && kCh[4] <= 128;
+    const bool acc_fwd = fuse_pool2 && !m->deterministic && kCh[4] <= 128 && !stream_capturing(s);
     unsigned fpar[4] = {0, 0, 0, 0};
     if (acc_fwd) {
         if (!R) R = const_cast<kws_model *>(m)->dev_res();
@@ -770,9 +773,10 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
     // in its epilogue and conv2's clip kernels derive k2 / k3 from the accumulator set.  Layer 3: conv4's data gradient adds its sums to the
     // set and the apply kernel derives the coefficients.  Layer 4: the fused Dense + head kernel's epilogue is the reduction, the apply
     // kernel expands the compact gradient.
-    const bool acc_bn2 = group_bwd && !det && routed_bwd2 && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
-    const bool acc_bn3 = group_bwd && !det;
-    const bool acc_bn4 = fused_head && dense_head_fused_ok(m, mprec) && !det && kCh[4] == kDhK && d.flat == d.H4 * d.W4 * kCh[4];
+    const bool acc_ok = !det && !stream_capturing(s);
+    const bool acc_bn2 = group_bwd && acc_ok && routed_bwd2 && Hs[1] * Ws[1] <= 160 && Hs[1] * Ws[1] * 8 <= 1280 && Hs[1] * Ws[1] * 4 <= 768;
+    const bool acc_bn3 = group_bwd && acc_ok;
+    const bool acc_bn4 = fused_head && dense_head_fused_ok(m, mprec) && acc_ok && kCh[4] == kDhK && d.flat == d.H4 * d.W4 * kCh[4];
     // parity of each layer's sets: flipped only by a pass that uses them (its consumer is what clears the other parity)
     const unsigned bpar[4] = {0u, acc_bn2 ? R->acc_uses[1][1]++ : 0u, acc_bn3 ? R->acc_uses[1][2]++ : 0u, acc_bn4 ? R->acc_uses[1][3]++ : 0u};
     KWS_TRY(acc_make_clean(R, s));
@@ -1036,7 +1040,7 @@ int cnn_backward(const kws_model *m, const float *feat, int B, const float *para
             // the default map (30 frames x 20 coefficients) has a fully unrolled form with its own window walk (kws_layer1_fast.h)
             // non-deterministic mode, default map: the kernel's last block evaluates the closed forms itself (no finalize launch); layer 0's
             // backward set of the model's accumulators holds the sums, its last word the ticket counter (kAccSlots * kL1BwdRows < kAccDoubles)
-            const bool fin_in_kernel = !det && d.H0 == 30 && d.W0 == 20;
+            const bool fin_in_kernel = acc_ok && d.H0 == 30 && d.W0 == 20;
             if (fin_in_kernel) {
                 double *acc0 = acc_set(R, 1, 0, 0);
                 const L1FinalizeArgs fin{acc0, reinterpret_cast<unsigned *>(acc0 + kAccDoubles - 1), q, params + m->o_g[0], grads + m->o_k[0],
